@@ -1,0 +1,110 @@
+/*
+ * ako_hip.h -- C-ABI of the MI355X (gfx950) transform path of libako.
+ *
+ * This is the "internal seam" of the reference codec turned into a device contract.  Per tile the
+ * reference runs (library/ako-private.h:47-51,81-84; call sites library/encode.c:132-148 and
+ * library/decode.c:183-205):
+ *
+ *     akoFormatToPlanarI16Yuv(...)  +  akoLift(...)          u8 tile window  ->  coefficient stream
+ *     akoUnlift(...)  +  akoFormatToInterleavedU8Rgb(...)    coefficient stream  ->  u8 tile window
+ *
+ * Here the same two mappings are offered for a whole BATCH of equally sized images at once, with
+ * inputs and outputs resident in device memory (or in host memory through the *Host variants).
+ * A "stream" is exactly the byte sequence the reference places in a blob when
+ * compression == AKO_COMPRESSION_NONE (library/encode.c:151-152,177-182): for every tile in raster
+ * order, akoTileDataSize(tile_w, tile_h) * channels bytes laid out as in library/lifting.c:171-292 /
+ * library/misc.c:229-288.  The 16 byte file header and the entropy coder are NOT part of it.
+ *
+ * All functions are plain C: pointers, sizes, ints.  Functions returning int return 0 on success
+ * and an enum akoStatus value otherwise; akoHipLastError() gives a human readable reason for the
+ * calling thread.  Nothing here falls back to the CPU: without a HIP device every call fails.
+ */
+#ifndef AKO_HIP_H
+#define AKO_HIP_H
+
+#include "ako.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct akoHipPlan akoHipPlan;
+
+/* Number of usable HIP devices (0 when there is none or the runtime cannot initialise). */
+int akoHipDeviceCount(void);
+
+/* Reason of the last failure on this thread ("" if none). */
+const char* akoHipLastError(void);
+
+/*
+ * A plan fixes: device, settings, channel count, image size and batch size.  It owns the per level
+ * geometry / quantizer tables (library/lifting.c:182-211 via library/quantization.c:67-98 -- computed
+ * on the host), the tile table (library/misc.c:152-203) and the device scratch for the
+ * intermediate low-pass planes.  settings->color is taken as given; use akoHipEffectiveColor() to
+ * apply the encoder's YCOCG <-> YCOCG_Q rule (library/encode.c:59-64) first.
+ *
+ * hip_stream: a hipStream_t to launch on (e.g. the current PyTorch stream), or NULL for the
+ * device's default stream.  flags: AKO_HIP_PLAN_* bits.
+ */
+#define AKO_HIP_PLAN_PLANES_I16 1u /* lifting-only mode: "images" are int16 planes (channels planes of w x h), no \
+                                      colour transform, no saturation; decode writes int16 planes back */
+
+akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, size_t channels, size_t image_w,
+                             size_t image_h, size_t batch, void* hip_stream, unsigned flags,
+                             enum akoStatus* out_status);
+void akoHipPlanDestroy(akoHipPlan*);
+
+enum akoColor akoHipEffectiveColor(const struct akoSettings* settings);
+
+/* Sizes, per image of the batch. */
+size_t akoHipPlanImageBytes(const akoHipPlan*);  /* w * h * channels (x2 in PLANES_I16 mode) */
+size_t akoHipPlanStreamBytes(const akoHipPlan*); /* sum of the tile streams = blob size - 16 */
+size_t akoHipPlanTiles(const akoHipPlan*);       /* library/misc.c:192 */
+size_t akoHipPlanBatch(const akoHipPlan*);
+
+/* Tile t (raster order): origin, extent and where its stream sits inside the image's stream. */
+int akoHipPlanTileInfo(const akoHipPlan*, size_t tile, size_t* x, size_t* y, size_t* w, size_t* h,
+                       size_t* stream_offset, size_t* stream_bytes);
+
+/* Quantizer / gate actually used for (tile group of tile t, level, plane): what the reference's
+ * akoQuantization / akoGate return (library/quantization.c:67,84).  level 0 = largest. */
+int akoHipPlanLevels(const akoHipPlan*, size_t tile);
+int akoHipPlanQuant(const akoHipPlan*, size_t tile, size_t level, size_t channel, int* q, int* g);
+
+/*
+ * Device resident transforms, asynchronous on the plan's stream.
+ *   d_images : batch * akoHipPlanImageBytes   (interleaved u8, row pitch image_w * channels)
+ *   d_streams: batch * akoHipPlanStreamBytes
+ * Replaces akoFormatToPlanarI16Yuv + akoLift (encode) and akoUnlift + akoFormatToInterleavedU8Rgb
+ * (decode) for every tile of every image of the batch.
+ */
+int akoHipEncode(akoHipPlan*, const void* d_images, void* d_streams);
+int akoHipDecode(akoHipPlan*, const void* d_streams, void* d_images);
+int akoHipSynchronize(akoHipPlan*);
+
+/* The same with host buffers (pinned or pageable): H2D, kernels, D2H, synchronous. */
+int akoHipEncodeHost(akoHipPlan*, const void* h_images, void* h_streams);
+int akoHipDecodeHost(akoHipPlan*, const void* h_streams, void* h_images);
+
+/*
+ * Per-kernel timing for roofline reporting.  With profiling on, every kernel launch of
+ * akoHipEncode / akoHipDecode is bracketed by hipEvents on the plan's stream; after
+ * akoHipSynchronize the records of the LAST encode and decode calls can be read back.
+ */
+struct akoHipKernelRecord
+{
+	char name[48];     /* e.g. "fwd_level_dd137_first" */
+	float ms;          /* hipEventElapsedTime of this launch */
+	uint32_t level;    /* 0 = largest */
+	uint32_t group;    /* tile group: 0 interior, 1 right edge, 2 bottom edge, 3 corner */
+	uint64_t units;    /* samples (w*h*planes*tiles*batch) the launch transformed */
+	uint64_t bytes_rd; /* algorithmic bytes read by this launch */
+	uint64_t bytes_wr; /* algorithmic bytes written by this launch */
+};
+int akoHipPlanSetProfiling(akoHipPlan*, int enabled);
+size_t akoHipPlanKernelRecords(akoHipPlan*, int decode, struct akoHipKernelRecord* out, size_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKO_HIP_H */

@@ -1,0 +1,232 @@
+"""CPU: the oracle (oracle/ako_oracle.c) against the committed golden vectors.
+
+The vectors were produced by the COMPILED REFERENCE (tests/golden/make_golden.py), so a pass here
+pins the oracle to the reference without needing /root/reference at run time.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, case_input, case_settings, parse_case_id
+
+I16 = C.POINTER(C.c_int16)
+
+
+def _p(a):
+    return a.ctypes.data_as(I16)
+
+
+def test_small_blobs_bit_exact(po, golden_blobs, golden_sums):
+    ids = sorted({k.rsplit("/", 1)[0] for k in golden_blobs.files})
+    assert len(ids) >= 40
+    for cid in ids:
+        c = parse_case_id(cid)
+        img = case_input(po, c)
+        assert f"{po.adler32(img):08x}" == golden_sums["small"][cid]["input_adler32"], cid
+        blob, st = po.encode_image(case_settings(po, c), img)
+        assert st == 0 and blob is not None, cid
+        assert np.array_equal(blob, golden_blobs[cid + "/blob"]), cid
+        dec, _, st = po.decode_image(golden_blobs[cid + "/blob"])
+        assert st == 0 and np.array_equal(dec, golden_blobs[cid + "/dec"]), cid
+
+
+def test_grid_checksums(po, golden_sums):
+    for cid, exp in golden_sums["grid"].items():
+        c = parse_case_id(cid)
+        img = case_input(po, c)
+        assert f"{po.adler32(img):08x}" == exp["input_adler32"], cid
+        blob, st = po.encode_image(case_settings(po, c), img)
+        assert st == 0 and blob.size == exp["blob"]["bytes"], cid
+        assert f"{po.adler32(blob):08x}" == exp["blob"]["adler32"], cid
+        dec, _, _ = po.decode_image(blob)
+        assert f"{po.adler32(dec):08x}" == exp["decoded"]["adler32"], cid
+
+
+def test_config0_cdf53_q16_512_kagari_file(po, golden_sums):
+    """BASELINE configs[0]: akoenc -w CDF53 -q 16 on a 512x512 RGBA image -> byte-identical .ako."""
+    exp = golden_sums["kagari"]["cfg0_512_cdf53_q16"]
+    c = parse_case_id(exp["case"])
+    img = case_input(po, c)
+    blob, st = po.encode_image(case_settings(po, c, compression=0), img)
+    assert st == 0 and blob.size == exp["blob"]["bytes"] == 71825
+    assert f"{po.adler32(blob):08x}" == exp["blob"]["adler32"] == "5e6a6736"
+    dec, _, _ = po.decode_image(blob)
+    assert f"{po.adler32(dec):08x}" == exp["decoded"]["adler32"]
+
+
+def test_kagari_tiled_file(po, golden_sums):
+    exp = golden_sums["kagari"]["g0_300x200_dd137_q16_t64"]
+    c = parse_case_id(exp["case"])
+    blob, st = po.encode_image(case_settings(po, c, compression=0), case_input(po, c))
+    assert st == 0 and f"{po.adler32(blob):08x}" == exp["blob"]["adler32"]
+    dec, _, _ = po.decode_image(blob)
+    assert f"{po.adler32(dec):08x}" == exp["decoded"]["adler32"]
+
+
+@pytest.mark.slow
+def test_baseline_4096_dd137_q16g16(po, golden_sums):
+    exp = golden_sums["baseline"]["g0_4096_dd137_q16g16"]
+    c = parse_case_id(exp["case"])
+    blob, st = po.encode_image(case_settings(po, c), case_input(po, c))
+    assert st == 0 and blob.size == 134217832
+    assert f"{po.adler32(blob):08x}" == exp["blob"]["adler32"] == "c8298fb9"
+    dec, _, _ = po.decode_image(blob)
+    assert f"{po.adler32(dec):08x}" == exp["decoded"]["adler32"] == "abd01c4a"
+
+
+def test_quant_tables(po):
+    q = json.load(open(os.path.join(GOLDEN, "quant.json")))
+    L = po.lib()
+    n = 0
+    for key, rows in q.items():
+        tw, th = (int(v) for v in key.split("x"))
+        for factor, w, h, q1, q2, g1, g2 in rows:
+            assert L.orcQuantStep(factor, 1, tw, th, w, h) == q1
+            assert L.orcQuantStep(factor, 2, tw, th, w, h) == q2
+            assert L.orcGateStep(factor, 1, tw, th, w, h) == g1
+            assert L.orcGateStep(factor, 2, tw, th, w, h) == g2
+            n += 1
+    assert n > 200
+    # SURVEY A.5 spot values
+    assert L.orcQuantStep(16, 1, 4096, 4096, 4096, 4096) == 44
+    assert L.orcQuantStep(16, 2, 8192, 8192, 8192, 8192) == 175
+    assert L.orcQuantStep(0, 1, 64, 64, 64, 64) == 1 and L.orcGateStep(0, 1, 64, 64, 64, 64) == 0
+
+
+# ---- the reference's own 1-D test pattern (tests/dd137-test.c, tests/cdf53-test.c) -------------
+
+def _ref_test_sequence(kind, n, data):
+    """The two generators of the reference's unit tests (tests/dd137-test.c:225-238), restated."""
+    out, prev = [], 0
+    for i in range(n):
+        if kind == "linear":
+            v = ((i + data) & 0xFFFF)
+            v = v - 65536 if v >= 32768 else v
+            v = (v * 5 + 32768) % 65536 - 32768
+        else:
+            x = (prev + data + (i if i < 32768 else i - 65536)) & 0xFFFF
+            x ^= (x << 7) & 0xFFFF
+            x ^= x >> 9
+            x ^= (x << 8) & 0xFFFF
+            v = (1 + (x % 65534)) % 64
+        out.append(v)
+        prev = v
+    return out
+
+
+def test_known_answers_from_reference_unit_tests(po):
+    """Lp / Hp rows printed by the reference's dd137-test / cdf53-test == the oracle's."""
+    kat = json.load(open(os.path.join(GOLDEN, "kat_1d.json")))
+    L = po.lib()
+    checked = 0
+    for t in kat:
+        n = t["len"]
+        wv = {"dd137": 0, "cdf53": 1}[t["wavelet"]]
+        # rebuild the full input: the printout only shows the first 22 samples
+        full = None
+        for kind in ("random", "linear"):
+            for data in range(0, 8):
+                cand = _ref_test_sequence(kind, n, data)
+                if cand[:len(t["input"])] == t["input"]:
+                    full = cand
+        assert full is not None, (t["wavelet"], t["direction"], n)
+        src = np.array(full + [0], dtype=np.int16)
+        T = (n + 1) // 2
+        fake = n % 2
+        for wrap_name, rows in t["wraps"].items():
+            wrap = {"clamp": 0, "mirror": 1, "repeat": 2, "zero": 3}[wrap_name]
+            lp = np.zeros(T, np.int16)
+            hp = np.zeros(T, np.int16)
+            L.orcLift1d(wv, wrap, T, fake, _p(src), 1, _p(lp), 1, _p(hp), 1)
+            assert lp[:len(rows["lp"])].tolist() == rows["lp"], (t["wavelet"], t["direction"], n, wrap_name)
+            assert hp[:len(rows["hp"])].tolist() == rows["hp"], (t["wavelet"], t["direction"], n, wrap_name)
+            checked += 1
+    assert checked >= 100
+
+
+@pytest.mark.parametrize("wavelet,lengths", [(0, [22, 16, 13, 17, 512, 150, 300, 10, 11]),
+                                             (1, [22, 16, 13, 17, 512, 150, 300, 10, 9, 8, 7, 6, 5, 4, 3]),
+                                             (2, [22, 3, 4, 5, 300])])
+def test_1d_round_trip_like_reference_tests(po, wavelet, lengths):
+    """unlift(lift(x)) == x for every wrap mode (tests/dd137-test.c:97-120, tests/cdf53-test.c:246-258)."""
+    L = po.lib()
+    rng = np.random.default_rng(5)
+    for n in lengths:
+        for wrap in range(4):
+            for full_range in (False, True):
+                x = rng.integers(-32768 if full_range else 0, 32768 if full_range else 64, n, dtype=np.int16)
+                src = np.concatenate([x, np.zeros(1, np.int16)])
+                T, fake = (n + 1) // 2, n % 2
+                lp, hp = np.zeros(T, np.int16), np.zeros(T, np.int16)
+                ev, od = np.zeros(T, np.int16), np.zeros(T, np.int16)
+                L.orcLift1d(wavelet, wrap, T, fake, _p(src), 1, _p(lp), 1, _p(hp), 1)
+                L.orcUnlift1d(wavelet, wrap, T, _p(lp), 1, _p(hp), 1, _p(ev), 1, _p(od), 1)
+                back = np.empty(2 * T, np.int16)
+                back[0::2], back[1::2] = ev, od
+                assert np.array_equal(back[:n], x), (wavelet, n, wrap, full_range)
+
+
+def test_vertical_strided_does_not_bleed(po):
+    """Column lifting with neighbours set to a sentinel (tests/dd137-test.c:137,160)."""
+    L = po.lib()
+    rng = np.random.default_rng(11)
+    h, w = 22, 3
+    a = np.full((h, w), 99, np.int16)
+    a[:, 0] = rng.integers(0, 64, h)
+    lo = np.full((h // 2, w), 99, np.int16)
+    hi = np.full((h // 2, w), 99, np.int16)
+    for wv in (0, 1, 2):
+        for wrap in range(4):
+            L.orcLift1d(wv, wrap, h // 2, 0, _p(a), w, _p(lo), w, _p(hi), w)
+            assert (lo[:, 1:] == 99).all() and (hi[:, 1:] == 99).all()
+            ev = np.full((h // 2, w), 99, np.int16)
+            od = np.full((h // 2, w), 99, np.int16)
+            L.orcUnlift1d(wv, wrap, h // 2, _p(lo), w, _p(hi), w, _p(ev), w, _p(od), w)
+            assert np.array_equal(ev[:, 0], a[0::2, 0]) and np.array_equal(od[:, 0], a[1::2, 0])
+
+
+def test_lossless_round_trip_and_stream_size(po):
+    rng = np.random.default_rng(2)
+    for (w, h, ch, wv, tiles) in [(37, 29, 4, 0, 0), (64, 64, 3, 1, 0), (100, 75, 4, 2, 32), (11, 200, 1, 0, 8),
+                                  (131, 67, 2, 1, 64)]:
+        img = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+        for wrap in range(4):
+            s = po.settings(wavelet=wv, wrap=wrap, q=0, g=0, tiles=tiles)
+            blob, st = po.encode_image(s, img)
+            assert st == 0
+            dec, s2, st = po.decode_image(blob)
+            assert st == 0 and np.array_equal(dec, img)
+            assert s2.wavelet == wv and s2.wrap == wrap and s2.tiles_dimension == tiles
+
+
+def test_plane_lifting_only_round_trip(po):
+    """BASELINE configs[1] shape at a CPU-friendly size: G2 plane, all levels, forward then inverse."""
+    for (w, h) in [(256, 256), (100, 75), (17, 300)]:
+        plane = po.gen_plane(w * h).reshape(h, w)
+        for wv in (0, 1, 2):
+            for wrap in (0, 2):
+                stream = po.lift_plane(wv, wrap, plane)
+                assert stream.size * 2 == po.lib().orcTileStreamBytes(w, h)
+                back = po.unlift_plane(wv, wrap, w, h, stream)
+                assert np.array_equal(back, plane)
+
+
+def test_error_statuses(po):
+    img = np.zeros((16, 16, 4), np.uint8)
+    assert po.encode_image(po.settings(tiles=12), img)[1] == 4       # AKO_INVALID_TILES_DIMENSIONS
+    assert po.encode_image(po.settings(tiles=4), img)[1] == 4
+    assert po.encode_image(po.settings(wrap=7), img)[1] == 5         # AKO_INVALID_WRAP_MODE
+    assert po.encode_image(po.settings(wavelet=9), img)[1] == 6
+    bad = np.zeros(64, np.uint8)
+    assert po.decode_image(bad)[2] == 11                             # AKO_INVALID_MAGIC
+    blob, _ = po.encode_image(po.settings(), img)
+    blob2 = blob.copy()
+    blob2[3] = 9
+    assert po.decode_image(blob2)[2] == 12                           # AKO_UNSUPPORTED_VERSION
+    assert po.decode_image(blob[:100])[2] == 15                      # AKO_BROKEN_INPUT
+    # incompressible tile: Kagari's output capacity equals the raw size (compression.c:41)
+    noise = np.random.default_rng(0).integers(0, 256, (64, 64, 4), dtype=np.uint8)
+    assert po.encode_image(po.settings(q=0, compression=0), noise)[1] == 1   # AKO_ERROR
