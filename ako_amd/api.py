@@ -1,0 +1,327 @@
+"""Python mirror of the reference's ``ako.h`` interface, bound to ``libako.so`` over its C-ABI.
+
+Two levels, both thin:
+
+* :func:`encode` / :func:`decode` call ``akoEncodeExt`` / ``akoDecodeExt`` (include/ako.h;
+  reference library/encode.c:38, library/decode.c:38) on host buffers -- what ``akoenc`` /
+  ``akodec`` do (tools/akoenc.cpp:112-217, tools/akodec.cpp:100-154).
+* :class:`Plan` drives the device-resident C-ABI of include/ako_hip.h with ``torch`` CUDA tensors
+  (PyTorch is only used for device memory and streams).
+
+There is no CPU fallback anywhere: if ``libako.so`` is missing, or no HIP device is usable, the
+calls raise / return the library's error status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libako.so")
+
+# enum akoWavelet / akoColor / akoWrap / akoCompression / akoStatus (include/ako.h)
+DD137, CDF53, HAAR, WAVELET_NONE = 0, 1, 2, 3
+YCOCG, SUBTRACT_G, COLOR_NONE, YCOCG_Q = 0, 1, 2, 3
+CLAMP, MIRROR, REPEAT, ZERO = 0, 1, 2, 3
+KAGARI, MANBAVARAN, COMPRESSION_NONE = 0, 1, 2
+AKO_OK, AKO_ERROR = 0, 1
+PLAN_PLANES_I16 = 1
+
+EVENT_NAMES = {1: "FORMAT_START", 2: "FORMAT_END", 3: "WAVELET_START", 4: "WAVELET_END", 5: "COMPRESSION_START",
+               6: "COMPRESSION_END"}
+
+
+class AkoError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        msg = f"{where}: status {status} ({status_string(status)})"
+        if detail:
+            msg += f": {detail}"
+        super().__init__(msg)
+
+
+class Settings(C.Structure):
+    """struct akoSettings (include/ako.h)."""
+
+    _fields_ = [("wavelet", C.c_int), ("color", C.c_int), ("wrap", C.c_int), ("compression", C.c_int),
+                ("tiles_dimension", C.c_size_t), ("quantization", C.c_int), ("gate", C.c_int),
+                ("chroma_loss", C.c_int), ("discard_non_visible", C.c_int)]
+
+    def copy(self) -> "Settings":
+        out = Settings()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(Settings))
+        return out
+
+
+_EVENTS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p)
+
+
+class Callbacks(C.Structure):
+    """struct akoCallbacks (include/ako.h)."""
+
+    _fields_ = [("malloc", C.c_void_p), ("realloc", C.c_void_p), ("free", C.c_void_p), ("events", _EVENTS_FN),
+                ("events_data", C.c_void_p)]
+
+
+class KernelRecord(C.Structure):
+    """struct akoHipKernelRecord (include/ako_hip.h)."""
+
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("level", C.c_uint32), ("group", C.c_uint32),
+                ("units", C.c_uint64), ("bytes_rd", C.c_uint64), ("bytes_wr", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libako.so; loud failure when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m ako_amd.build` "
+                          "(there is no CPU fallback for the transform path)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.akoEncodeExt.restype = sz
+    L.akoEncodeExt.argtypes = [C.POINTER(Callbacks), C.POINTER(Settings), sz, sz, sz, vp, C.POINTER(vp),
+                               C.POINTER(C.c_int)]
+    L.akoDecodeExt.restype = vp
+    L.akoDecodeExt.argtypes = [C.POINTER(Callbacks), sz, vp, C.POINTER(Settings), C.POINTER(sz), C.POINTER(sz),
+                               C.POINTER(sz), C.POINTER(C.c_int)]
+    L.akoDefaultSettings.restype = Settings
+    L.akoDefaultCallbacks.restype = Callbacks
+    L.akoDefaultFree.argtypes = [vp]
+    L.akoDefaultFree.restype = None
+    L.akoStatusString.restype = C.c_char_p
+    L.akoStatusString.argtypes = [C.c_int]
+    for name in ("akoVersionMajor", "akoVersionMinor", "akoVersionPatch", "akoFormatVersion", "akoHipDeviceCount"):
+        getattr(L, name).restype = C.c_int
+    L.akoHipLastError.restype = C.c_char_p
+    L.akoHipEffectiveColor.restype = C.c_int
+    L.akoHipEffectiveColor.argtypes = [C.POINTER(Settings)]
+    L.akoHipPlanCreate.restype = vp
+    L.akoHipPlanCreate.argtypes = [C.c_int, C.POINTER(Settings), sz, sz, sz, sz, vp, C.c_uint, C.POINTER(C.c_int)]
+    L.akoHipPlanDestroy.argtypes = [vp]
+    L.akoHipPlanDestroy.restype = None
+    for name in ("akoHipPlanImageBytes", "akoHipPlanStreamBytes", "akoHipPlanTiles", "akoHipPlanBatch"):
+        f = getattr(L, name)
+        f.restype = sz
+        f.argtypes = [vp]
+    L.akoHipPlanTileInfo.restype = C.c_int
+    L.akoHipPlanTileInfo.argtypes = [vp, sz] + [C.POINTER(sz)] * 6
+    L.akoHipPlanLevels.restype = C.c_int
+    L.akoHipPlanLevels.argtypes = [vp, sz]
+    L.akoHipPlanQuant.restype = C.c_int
+    L.akoHipPlanQuant.argtypes = [vp, sz, sz, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for name in ("akoHipEncode", "akoHipDecode", "akoHipEncodeHost", "akoHipDecodeHost"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [vp, vp, vp]
+    L.akoHipSynchronize.restype = C.c_int
+    L.akoHipSynchronize.argtypes = [vp]
+    L.akoHipPlanSetProfiling.restype = C.c_int
+    L.akoHipPlanSetProfiling.argtypes = [vp, C.c_int]
+    L.akoHipPlanKernelRecords.restype = sz
+    L.akoHipPlanKernelRecords.argtypes = [vp, C.c_int, C.POINTER(KernelRecord), sz]
+    # host-side helpers (exported for the host-logic tests)
+    L.akoHostQuantStep.restype = C.c_int16
+    L.akoHostQuantStep.argtypes = [C.c_int, C.c_int, sz, sz, sz, sz]
+    L.akoHostGateStep.restype = C.c_int16
+    L.akoHostGateStep.argtypes = [C.c_int, C.c_int, sz, sz, sz, sz]
+    L.akoHostHeadWrite.restype = C.c_int
+    L.akoHostHeadWrite.argtypes = [sz, sz, sz, C.POINTER(Settings), vp]
+    L.akoHostHeadRead.restype = C.c_int
+    L.akoHostHeadRead.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(Settings)]
+    L.akoHostKagariEncode.restype = sz
+    L.akoHostKagariEncode.argtypes = [sz, sz, vp, vp]
+    L.akoHostKagariDecode.restype = sz
+    L.akoHostKagariDecode.argtypes = [sz, sz, sz, vp, vp]
+    _lib = L
+    return L
+
+
+def status_string(status: int) -> str:
+    try:
+        return lib().akoStatusString(int(status)).decode()
+    except Exception:  # library missing: still give the number
+        return "?"
+
+
+def default_settings() -> Settings:
+    return lib().akoDefaultSettings()
+
+
+def settings(wavelet=DD137, color=YCOCG, wrap=CLAMP, compression=KAGARI, tiles=0, q=16, g=0, chroma_loss=1,
+             discard=0) -> Settings:
+    return Settings(wavelet, color, wrap, compression, tiles, q, g, chroma_loss, discard)
+
+
+def device_count() -> int:
+    return lib().akoHipDeviceCount()
+
+
+def last_error() -> str:
+    return lib().akoHipLastError().decode()
+
+
+# ---------------------------------------------------------------------------------------------
+# ako.h level: host buffers in, host buffers out
+# ---------------------------------------------------------------------------------------------
+
+def _callbacks(events: Optional[Callable[[int, int, int], None]]):
+    cb = lib().akoDefaultCallbacks()
+    keep = None
+    if events is not None:
+        keep = _EVENTS_FN(lambda tile, total, ev, _data: events(int(tile), int(total), int(ev)))
+        cb.events = keep
+    return cb, keep
+
+
+def encode(image: np.ndarray, s: Optional[Settings] = None, events=None) -> np.ndarray:
+    """akoEncodeExt on an (h, w, channels) or (h, w) uint8 array -> blob (uint8 array)."""
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = image.shape[:2]
+    ch = 1 if image.ndim == 2 else image.shape[2]
+    cb, keep = _callbacks(events)
+    out = C.c_void_p()
+    st = C.c_int(-1)
+    n = lib().akoEncodeExt(C.byref(cb), C.byref(s) if s is not None else None, ch, w, h,
+                           image.ctypes.data_as(C.c_void_p), C.byref(out), C.byref(st))
+    del keep
+    if n == 0:
+        raise AkoError(st.value, "akoEncodeExt", last_error())
+    blob = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    lib().akoDefaultFree(out)
+    return blob
+
+
+def decode(blob, events=None):
+    """akoDecodeExt -> (image (h, w, channels) uint8, Settings)."""
+    blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray)) else blob,
+                                dtype=np.uint8)
+    cb, keep = _callbacks(events)
+    s = Settings()
+    ch, w, h = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    st = C.c_int(-1)
+    p = lib().akoDecodeExt(C.byref(cb), blob.size, blob.ctypes.data_as(C.c_void_p), C.byref(s), C.byref(ch),
+                           C.byref(w), C.byref(h), C.byref(st))
+    del keep
+    if not p:
+        raise AkoError(st.value, "akoDecodeExt", last_error())
+    img = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, ch.value)).copy()
+    lib().akoDefaultFree(p)
+    return img, s
+
+
+# ---------------------------------------------------------------------------------------------
+# ako_hip.h level: device resident batches
+# ---------------------------------------------------------------------------------------------
+
+class Plan:
+    """akoHipPlan wrapper.  Tensors are torch CUDA tensors on the plan's device.
+
+    images : uint8 [batch, h, w, channels]            (int16 [batch, channels, h, w] with planes_i16)
+    streams: int16 [batch, stream_bytes // 2]
+    """
+
+    def __init__(self, s: Settings, channels: int, w: int, h: int, batch: int = 1, device: int = 0,
+                 stream: Optional[int] = None, planes_i16: bool = False, effective_color: bool = True):
+        import torch  # device memory / stream plumbing only
+
+        self._torch = torch
+        self.settings = s.copy()
+        if effective_color:
+            self.settings.color = lib().akoHipEffectiveColor(C.byref(self.settings))
+        self.channels, self.w, self.h, self.batch, self.device = channels, w, h, batch, device
+        self.planes_i16 = planes_i16
+        if stream is None:
+            stream = torch.cuda.current_stream(device).cuda_stream
+        st = C.c_int(-1)
+        self._p = lib().akoHipPlanCreate(device, C.byref(self.settings), channels, w, h, batch, C.c_void_p(stream),
+                                         PLAN_PLANES_I16 if planes_i16 else 0, C.byref(st))
+        if not self._p:
+            raise AkoError(st.value, "akoHipPlanCreate", last_error())
+        self.image_bytes = lib().akoHipPlanImageBytes(self._p)
+        self.stream_bytes = lib().akoHipPlanStreamBytes(self._p)
+        self.tiles = lib().akoHipPlanTiles(self._p)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib().akoHipPlanDestroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            raise AkoError(rc, where, last_error())
+
+    def new_streams(self):
+        t = self._torch
+        return t.empty((self.batch, self.stream_bytes // 2), dtype=t.int16, device=f"cuda:{self.device}")
+
+    def new_images(self):
+        t = self._torch
+        if self.planes_i16:
+            return t.empty((self.batch, self.channels, self.h, self.w), dtype=t.int16, device=f"cuda:{self.device}")
+        return t.empty((self.batch, self.h, self.w, self.channels), dtype=t.uint8, device=f"cuda:{self.device}")
+
+    def encode(self, images, streams=None):
+        """akoHipEncode: asynchronous on the plan's stream."""
+        assert images.is_cuda and images.is_contiguous()
+        assert images.numel() * images.element_size() == self.image_bytes * self.batch
+        if streams is None:
+            streams = self.new_streams()
+        assert streams.is_cuda and streams.is_contiguous()
+        assert streams.numel() * streams.element_size() == self.stream_bytes * self.batch
+        self._check(lib().akoHipEncode(self._p, C.c_void_p(images.data_ptr()), C.c_void_p(streams.data_ptr())),
+                    "akoHipEncode")
+        return streams
+
+    def decode(self, streams, images=None):
+        """akoHipDecode: asynchronous on the plan's stream."""
+        assert streams.is_cuda and streams.is_contiguous()
+        assert streams.numel() * streams.element_size() == self.stream_bytes * self.batch
+        if images is None:
+            images = self.new_images()
+        assert images.is_cuda and images.is_contiguous()
+        assert images.numel() * images.element_size() == self.image_bytes * self.batch
+        self._check(lib().akoHipDecode(self._p, C.c_void_p(streams.data_ptr()), C.c_void_p(images.data_ptr())),
+                    "akoHipDecode")
+        return images
+
+    def synchronize(self):
+        self._check(lib().akoHipSynchronize(self._p), "akoHipSynchronize")
+
+    def tile_info(self, t: int):
+        v = [C.c_size_t() for _ in range(6)]
+        self._check(lib().akoHipPlanTileInfo(self._p, t, *[C.byref(x) for x in v]), "akoHipPlanTileInfo")
+        return dict(zip(("x", "y", "w", "h", "stream_offset", "stream_bytes"), (x.value for x in v)))
+
+    def levels(self, tile: int = 0) -> int:
+        return lib().akoHipPlanLevels(self._p, tile)
+
+    def quant(self, tile: int, level: int, channel: int):
+        q, g = C.c_int(), C.c_int()
+        self._check(lib().akoHipPlanQuant(self._p, tile, level, channel, C.byref(q), C.byref(g)), "akoHipPlanQuant")
+        return q.value, g.value
+
+    def set_profiling(self, on: bool):
+        lib().akoHipPlanSetProfiling(self._p, 1 if on else 0)
+
+    def kernel_records(self, decode: bool):
+        buf = (KernelRecord * 8192)()
+        n = lib().akoHipPlanKernelRecords(self._p, 1 if decode else 0, buf, 8192)
+        return [dict(name=buf[i].name.decode(), ms=buf[i].ms, level=buf[i].level, group=buf[i].group,
+                     units=buf[i].units, bytes_rd=buf[i].bytes_rd, bytes_wr=buf[i].bytes_wr) for i in range(n)]

@@ -1,0 +1,64 @@
+"""Build libako.so (HIP kernels for gfx950 + C-ABI + host C drivers) in-tree.
+
+    python -m ako_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting ako_amd/libako.so travels to the GPU
+box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libako.so")
+OBJ = os.path.join(HERE, "csrc", "build")
+
+HIP_SOURCES = ["ako_plan.hip"]
+HIP_HEADERS = ["ako_kernels.hip.h"]
+C_SOURCES = ["host/ako_quant.c", "host/ako_head.c", "host/ako_misc.c", "host/ako_kagari.c", "host/ako_codec.c"]
+C_HEADERS = ["host/ako_host.h", "../../include/ako.h", "../../include/ako_hip.h"]
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd: list[str]) -> None:
+    print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    hip_deps = [os.path.join(CSRC, h) for h in HIP_HEADERS + C_HEADERS]
+    for src in HIP_SOURCES:
+        o = os.path.join(OBJ, os.path.basename(src) + ".o")
+        if force or _stale(o, [os.path.join(CSRC, src)] + hip_deps):
+            _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                  "-Wall", "-Wno-unused-function"] + (extra_hip_flags or []) +
+                 ["-c", os.path.join(CSRC, src), "-o", o])
+        objs.append(o)
+    c_deps = [os.path.join(CSRC, h) for h in C_HEADERS]
+    for src in C_SOURCES:
+        o = os.path.join(OBJ, os.path.basename(src) + ".o")
+        if force or _stale(o, [os.path.join(CSRC, src)] + c_deps):
+            _run(["gcc", "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wextra",
+                  "-c", os.path.join(CSRC, src), "-o", o])
+        objs.append(o)
+    if force or _stale(OUT, objs):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs + ["-lm"])
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

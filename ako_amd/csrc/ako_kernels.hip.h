@@ -301,7 +301,9 @@ __global__ __launch_bounds__(THREADS) void k_forward_level(const LevelParams P)
 			int16_t s = 0;
 			if (!zero)
 			{
-				const int16_t* base = P.src + inst * P.src_inst_stride + (uint64_t)p_first * P.src_plane_stride;
+				// scratch planes are per tile instance; in PLANES_I16 mode the source is the image itself
+				const int16_t* base = P.src + (P.src_tiled ? (uint64_t)id.image : inst) * P.src_inst_stride +
+				                      (uint64_t)p_first * P.src_plane_stride;
 				if (P.src_tiled)
 					base += (uint64_t)td.y0 * P.src_pitch + td.x0;
 				s = base[(uint64_t)y * P.src_pitch + x];
@@ -536,7 +538,8 @@ __global__ __launch_bounds__(THREADS) void k_inverse_level(const LevelParams P)
 		}
 		else
 		{
-			int16_t* out = P.dst + inst * P.dst_inst_stride + (uint64_t)p_first * P.dst_plane_stride;
+			int16_t* out = P.dst + (P.dst_tiled ? (uint64_t)id.image : inst) * P.dst_inst_stride +
+			               (uint64_t)p_first * P.dst_plane_stride;
 			if (P.dst_tiled)
 				out += (uint64_t)td.y0 * P.dst_pitch + td.x0;
 			out[(uint64_t)y * P.dst_pitch + x] = cell[0];

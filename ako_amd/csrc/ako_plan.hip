@@ -1,0 +1,787 @@
+// ako_plan.hip -- host side of the device path: plans, launch sequencing, C-ABI (include/ako_hip.h).
+//
+// The level loop that the reference runs per tile on the CPU (library/lifting.c:182-291 forward,
+// library/misc.c:229-288 inverse) becomes, per GROUP of equally sized tiles, one kernel launch per
+// level covering every tile of every image of the batch and every plane.  Geometry, stream offsets
+// and the float quantizer / gate scalars (library/quantization.c:43-98) are prepared once per plan
+// on the host.
+#include "ako_kernels.hip.h"
+
+#include "../../include/ako_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+extern "C" {
+// host C (ako_host.c): same float recipe as library/quantization.c
+int16_t akoHostQuantStep(int factor, int mul, size_t tile_w, size_t tile_h, size_t cur_w, size_t cur_h);
+int16_t akoHostGateStep(int factor, int mul, size_t tile_w, size_t tile_h, size_t cur_w, size_t cur_h);
+}
+
+using namespace ako;
+
+namespace
+{
+
+thread_local std::string g_last_error;
+
+int fail(enum akoStatus st, const char* fmt, const char* a = "", const char* b = "")
+{
+	char buf[512];
+	snprintf(buf, sizeof buf, fmt, a, b);
+	g_last_error = buf;
+	return (int)st;
+}
+
+#define HIP_TRY(expr)                                                                   \
+	do                                                                                  \
+	{                                                                                   \
+		hipError_t e_ = (expr);                                                         \
+		if (e_ != hipSuccess)                                                           \
+			return fail(AKO_ERROR, "HIP error: %s at %s", hipGetErrorString(e_), #expr); \
+	} while (0)
+
+struct LevelGeom
+{
+	uint32_t cw, ch, tw, th;  // current (input) and target (sub-band) extents: lifting.c:184-187
+	int kind;                 // wavelet after the DD137 -> CDF53 fallback: lifting.c:58
+	int q[2], g[2];           // [0] plane 0, [1] every other plane: lifting.c:202-211
+	uint64_t grp_off[MAX_CH];
+};
+
+struct Group
+{
+	uint32_t tile_w = 0, tile_h = 0;
+	uint32_t fw = 0, fh = 0;  // final low-pass extent
+	std::vector<LevelGeom> levels;
+	uint64_t lp_off[MAX_CH];
+	uint64_t tile_values = 0;  // int16 per tile stream
+	std::vector<TileDesc> tiles;
+	TileDesc* d_tiles = nullptr;
+};
+
+struct TileInfo
+{
+	size_t x, y, w, h, stream_off, stream_bytes;
+	int group;
+};
+
+struct EventPair
+{
+	hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct akoHipPlan
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	struct akoSettings s;
+	size_t channels = 0, w = 0, h = 0, batch = 0;
+	unsigned flags = 0;
+	std::vector<Group> groups;
+	std::vector<TileInfo> tiles;
+	size_t stream_values = 0;  // int16 per image
+	int16_t* scratch[2] = {nullptr, nullptr};
+	size_t scratch_elems[2] = {0, 0};
+	// host-variant staging
+	void* d_img = nullptr;
+	void* d_stream = nullptr;
+	// profiling
+	bool profiling = false;
+	std::vector<EventPair> events[2];  // [0] encode launches, [1] decode launches
+	size_t events_used[2] = {0, 0};
+	struct Pending
+	{
+		akoHipKernelRecord rec;
+		size_t ev;
+	};
+	std::vector<Pending> pending[2];
+};
+
+namespace
+{
+
+size_t half_up(size_t v)  // misc.c:98
+{
+	return (v + 1) / 2;
+}
+
+size_t tile_extent(size_t pos, size_t image_d, size_t td)  // misc.c:152
+{
+	if (td == 0)
+		return image_d;
+	return (pos + td > image_d) ? (image_d % td) : td;
+}
+
+void build_group(Group& g, const akoSettings& s, size_t channels)
+{
+	size_t w = g.tile_w, h = g.tile_h;
+	if (s.wavelet != AKO_WAVELET_NONE)
+	{
+		while (w > 2 && h > 2)  // lifting.c:182
+		{
+			LevelGeom L;
+			L.cw = (uint32_t)w, L.ch = (uint32_t)h;
+			w = half_up(w), h = half_up(h);
+			L.tw = (uint32_t)w, L.th = (uint32_t)h;
+			if (s.wavelet == AKO_WAVELET_HAAR)
+				L.kind = K_HAAR;
+			else if (s.wavelet == AKO_WAVELET_CDF53 || w < 8 || h < 8)
+				L.kind = K_CDF53;
+			else
+				L.kind = K_DD137;
+			for (int m = 0; m < 2; m++)
+			{
+				const int mul = (m == 0) ? 1 : s.chroma_loss + 1;
+				L.q[m] = akoHostQuantStep(s.quantization, mul, g.tile_w, g.tile_h, L.cw, L.ch);
+				L.g[m] = akoHostGateStep(s.gate, mul, g.tile_w, g.tile_h, L.cw, L.ch);
+			}
+			g.levels.push_back(L);
+		}
+	}
+	g.fw = (uint32_t)w, g.fh = (uint32_t)h;
+
+	// stream layout (misc.c:245-285): low-passes of all planes, then levels small -> large,
+	// planes 0 .. N-1, each [head C B D]
+	uint64_t off = 0;
+	for (size_t p = 0; p < channels; p++)
+	{
+		g.lp_off[p] = off;
+		off += (uint64_t)w * h;
+	}
+	for (size_t l = g.levels.size(); l-- > 0;)
+		for (size_t p = 0; p < channels; p++)
+		{
+			g.levels[l].grp_off[p] = off;
+			off += 1 + 3 * (uint64_t)g.levels[l].tw * g.levels[l].th;
+		}
+	g.tile_values = off;
+}
+
+struct Launch
+{
+	akoHipPlan* plan;
+	int decode;
+	size_t ev = (size_t)-1;
+
+	int begin()
+	{
+		if (!plan->profiling)
+			return 0;
+		if (plan->events_used[decode] == plan->events[decode].size())
+		{
+			EventPair p;
+			HIP_TRY(hipEventCreate(&p.a));
+			HIP_TRY(hipEventCreate(&p.b));
+			plan->events[decode].push_back(p);
+		}
+		ev = plan->events_used[decode]++;
+		HIP_TRY(hipEventRecord(plan->events[decode][ev].a, plan->stream));
+		return 0;
+	}
+	int end(const char* name, uint32_t level, uint32_t group, uint64_t units, uint64_t rd, uint64_t wr)
+	{
+		HIP_TRY(hipGetLastError());
+		if (!plan->profiling)
+			return 0;
+		HIP_TRY(hipEventRecord(plan->events[decode][ev].b, plan->stream));
+		akoHipPlan::Pending p;
+		memset(&p.rec, 0, sizeof p.rec);
+		snprintf(p.rec.name, sizeof p.rec.name, "%s", name);
+		p.rec.level = level, p.rec.group = group, p.rec.units = units, p.rec.bytes_rd = rd, p.rec.bytes_wr = wr;
+		p.ev = ev;
+		plan->pending[decode].push_back(p);
+		return 0;
+	}
+};
+
+const char* kind_name(int k)
+{
+	return k == K_DD137 ? "dd137" : (k == K_CDF53 ? "cdf53" : "haar");
+}
+
+void fill_common(LevelParams& P, const akoHipPlan* pl, const Group& g, const LevelGeom& L)
+{
+	memset(&P, 0, sizeof P);
+	P.full_w = L.cw, P.full_h = L.ch, P.sub_w = L.tw, P.sub_h = L.th;
+	P.wrap = (int)pl->s.wrap;
+	P.channels = (uint32_t)pl->channels;
+	P.grid_x = (L.tw + TW - 1) / TW, P.grid_y = (L.th + TH - 1) / TH;
+	P.tiles = g.d_tiles;
+	P.n_tiles = (uint32_t)g.tiles.size();
+	P.batch = (uint32_t)pl->batch;
+	P.img_pitch = (uint32_t)pl->w;
+	P.img_stride = (uint64_t)pl->w * pl->h * pl->channels;
+	P.color = (int)pl->s.color;
+	P.discard = pl->s.discard_non_visible;
+	P.stream_stride = pl->stream_values;
+	for (size_t p = 0; p < pl->channels; p++)
+	{
+		P.lp_off[p] = g.lp_off[p];
+		P.grp_off[p] = L.grp_off[p];
+	}
+	P.q_luma = L.q[0], P.g_luma = L.g[0], P.q_chroma = L.q[1], P.g_chroma = L.g[1];
+	P.rq_luma = (float)((1.0 / (double)(L.q[0] < 1 ? 1 : L.q[0])) * (1.0 + 1e-6));
+	P.rq_chroma = (float)((1.0 / (double)(L.q[1] < 1 ? 1 : L.q[1])) * (1.0 + 1e-6));
+}
+
+template <bool U8>
+void launch_forward(int kind, const LevelParams& P, uint32_t blocks, size_t smem, hipStream_t st)
+{
+	switch (kind)
+	{
+	case K_DD137: hipLaunchKernelGGL((k_forward_level<K_DD137, U8>), dim3(blocks), dim3(THREADS), smem, st, P); break;
+	case K_CDF53: hipLaunchKernelGGL((k_forward_level<K_CDF53, U8>), dim3(blocks), dim3(THREADS), smem, st, P); break;
+	default: hipLaunchKernelGGL((k_forward_level<K_HAAR, U8>), dim3(blocks), dim3(THREADS), smem, st, P); break;
+	}
+}
+
+template <bool U8>
+void launch_inverse(int kind, const LevelParams& P, uint32_t blocks, size_t smem, hipStream_t st)
+{
+	switch (kind)
+	{
+	case K_DD137: hipLaunchKernelGGL((k_inverse_level<K_DD137, U8>), dim3(blocks), dim3(THREADS), smem, st, P); break;
+	case K_CDF53: hipLaunchKernelGGL((k_inverse_level<K_CDF53, U8>), dim3(blocks), dim3(THREADS), smem, st, P); break;
+	default: hipLaunchKernelGGL((k_inverse_level<K_HAAR, U8>), dim3(blocks), dim3(THREADS), smem, st, P); break;
+	}
+}
+
+int check_blocks(uint64_t blocks)
+{
+	if (blocks == 0 || blocks > 0x7FFFFFFFull)
+		return fail(AKO_ERROR, "launch too large for one grid%s%s");
+	return 0;
+}
+
+// int16 planes per tile instance held by scratch buffer 'which' for group g
+uint64_t scratch_plane_elems(const Group& g, int which)
+{
+	if ((int)g.levels.size() <= which)
+		return 0;
+	return (uint64_t)g.levels[which].tw * g.levels[which].th;
+}
+
+int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream)
+{
+	const Group& g = pl->groups[gi];
+	FormatParams F;
+	memset(&F, 0, sizeof F);
+	F.tile_w = g.tile_w, F.tile_h = g.tile_h, F.channels = (uint32_t)pl->channels;
+	F.tiles = g.d_tiles, F.n_tiles = (uint32_t)g.tiles.size(), F.batch = (uint32_t)pl->batch;
+	F.img = img, F.img_stride = (uint64_t)pl->w * pl->h * pl->channels, F.img_pitch = (uint32_t)pl->w;
+	F.color = (int)pl->s.color, F.discard = pl->s.discard_non_visible;
+	F.stream = stream, F.stream_stride = pl->stream_values;
+	const uint64_t npx = (uint64_t)g.tile_w * g.tile_h;
+	const uint64_t blocks = ((npx + THREADS - 1) / THREADS) * g.tiles.size() * pl->batch;
+	if (int rc = check_blocks(blocks))
+		return rc;
+	Launch L{pl, decode};
+	if (int rc = L.begin())
+		return rc;
+	if (decode)
+		hipLaunchKernelGGL(k_format_inverse, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
+	else
+		hipLaunchKernelGGL(k_format_forward, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
+	const uint64_t units = npx * pl->channels * g.tiles.size() * pl->batch;
+	return L.end(decode ? "format_inverse" : "format_forward", 0, (uint32_t)gi, units, decode ? units * 2 : units,
+	             decode ? units : units * 2);
+}
+
+int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
+{
+	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
+	for (size_t gi = 0; gi < pl->groups.size(); gi++)
+	{
+		const Group& g = pl->groups[gi];
+		if (pl->s.wavelet == AKO_WAVELET_NONE)
+		{
+			if (planes)
+				return fail(AKO_ERROR, "PLANES_I16 mode needs a wavelet%s%s");
+			if (int rc = run_format(pl, (int)gi, 0, (uint8_t*)d_images, (int16_t*)d_streams))
+				return rc;
+			continue;
+		}
+		if (g.levels.empty())
+			return fail(AKO_ERROR, "tile with an extent <= 2 cannot be encoded (reference mis-reads it: lifting.c:285)%s%s");
+
+		const size_t nl = g.levels.size();
+		const uint64_t insts = (uint64_t)g.tiles.size() * pl->batch;
+		for (size_t l = 0; l < nl; l++)
+		{
+			const LevelGeom& L = g.levels[l];
+			LevelParams P;
+			fill_common(P, pl, g, L);
+			P.stream = (int16_t*)d_streams;
+			const bool u8 = (l == 0) && !planes;
+			if (u8)
+			{
+				P.img = (uint8_t*)d_images;
+				P.planes_per_wg = (uint32_t)(pl->channels < 4 ? pl->channels : 4);
+			}
+			else
+			{
+				P.planes_per_wg = 1;
+				if (l == 0)
+				{
+					P.src = (const int16_t*)d_images;
+					P.src_tiled = 1;
+					P.src_pitch = (uint32_t)pl->w;
+					P.src_plane_stride = (uint64_t)pl->w * pl->h;
+					P.src_inst_stride = P.src_plane_stride * pl->channels;
+				}
+				else
+				{
+					const int which = (int)((l - 1) & 1);
+					P.src = pl->scratch[which];
+					P.src_pitch = L.cw;
+					P.src_plane_stride = scratch_plane_elems(g, which);
+					P.src_inst_stride = P.src_plane_stride * pl->channels;
+				}
+			}
+			P.plane_groups = (uint32_t)((pl->channels + P.planes_per_wg - 1) / P.planes_per_wg);
+			if (l + 1 == nl)
+				P.ll_out_stream = 1;
+			else
+			{
+				const int which = (int)(l & 1);
+				P.dst = pl->scratch[which];
+				P.dst_pitch = L.tw;
+				P.dst_plane_stride = scratch_plane_elems(g, which);
+				P.dst_inst_stride = P.dst_plane_stride * pl->channels;
+			}
+
+			const uint64_t blocks = (uint64_t)P.grid_x * P.grid_y * P.plane_groups * insts;
+			if (int rc = check_blocks(blocks))
+				return rc;
+			const size_t smem = (size_t)P.planes_per_wg * WPLANE * sizeof(int16_t);
+			Launch LA{pl, 0};
+			if (int rc = LA.begin())
+				return rc;
+			if (u8)
+				launch_forward<true>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+			else
+				launch_forward<false>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+			char name[48];
+			snprintf(name, sizeof name, "fwd_level_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			const uint64_t samples = (uint64_t)L.cw * L.ch * pl->channels * insts;
+			const uint64_t outs = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
+			if (int rc = LA.end(name, (uint32_t)l, (uint32_t)gi, samples, samples * (u8 ? 1 : 2), outs * 2))
+				return rc;
+		}
+	}
+	return 0;
+}
+
+int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
+{
+	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
+	for (size_t gi = 0; gi < pl->groups.size(); gi++)
+	{
+		const Group& g = pl->groups[gi];
+		if (pl->s.wavelet == AKO_WAVELET_NONE || g.levels.empty())
+		{
+			if (planes)
+				return fail(AKO_ERROR, "PLANES_I16 mode needs at least one lift%s%s");
+			if (int rc = run_format(pl, (int)gi, 1, (uint8_t*)d_images, (int16_t*)d_streams))
+				return rc;
+			continue;
+		}
+
+		const size_t nl = g.levels.size();
+		const uint64_t insts = (uint64_t)g.tiles.size() * pl->batch;
+		for (size_t l = nl; l-- > 0;)
+		{
+			const LevelGeom& L = g.levels[l];
+			LevelParams P;
+			fill_common(P, pl, g, L);
+			P.stream = (int16_t*)d_streams;
+			const bool u8 = (l == 0) && !planes;
+			P.planes_per_wg = u8 ? (uint32_t)(pl->channels < 4 ? pl->channels : 4) : 1;
+			P.plane_groups = (uint32_t)((pl->channels + P.planes_per_wg - 1) / P.planes_per_wg);
+
+			if (l + 1 == nl)
+				P.ll_in_stream = 1;
+			else
+			{
+				const int which = (int)(l & 1);
+				P.src = pl->scratch[which];
+				P.src_pitch = L.tw;
+				P.src_plane_stride = scratch_plane_elems(g, which);
+				P.src_inst_stride = P.src_plane_stride * pl->channels;
+			}
+			if (u8)
+				P.img = (uint8_t*)d_images;
+			else if (l == 0)
+			{
+				P.dst = (int16_t*)d_images;
+				P.dst_tiled = 1;
+				P.dst_pitch = (uint32_t)pl->w;
+				P.dst_plane_stride = (uint64_t)pl->w * pl->h;
+				P.dst_inst_stride = P.dst_plane_stride * pl->channels;
+			}
+			else
+			{
+				const int which = (int)((l - 1) & 1);
+				P.dst = pl->scratch[which];
+				P.dst_pitch = L.cw;
+				P.dst_plane_stride = scratch_plane_elems(g, which);
+				P.dst_inst_stride = P.dst_plane_stride * pl->channels;
+			}
+
+			const uint64_t blocks = (uint64_t)P.grid_x * P.grid_y * P.plane_groups * insts;
+			if (int rc = check_blocks(blocks))
+				return rc;
+			const size_t smem = (size_t)P.planes_per_wg * WPLANE * sizeof(int16_t);
+			Launch LA{pl, 1};
+			if (int rc = LA.begin())
+				return rc;
+			if (u8)
+				launch_inverse<true>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+			else
+				launch_inverse<false>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+			char name[48];
+			snprintf(name, sizeof name, "inv_level_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			const uint64_t samples = (uint64_t)L.cw * L.ch * pl->channels * insts;
+			const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
+			if (int rc = LA.end(name, (uint32_t)l, (uint32_t)gi, samples, ins * 2, samples * (u8 ? 1 : 2)))
+				return rc;
+		}
+	}
+	return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int akoHipDeviceCount(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return 0;
+	}
+	return n;
+}
+
+const char* akoHipLastError(void)
+{
+	return g_last_error.c_str();
+}
+
+enum akoColor akoHipEffectiveColor(const struct akoSettings* s)  // encode.c:59-64
+{
+	if (s->color == AKO_COLOR_YCOCG && (s->quantization > 0 || s->gate > 0))
+		return AKO_COLOR_YCOCG_Q;
+	if (s->color == AKO_COLOR_YCOCG_Q && (s->quantization <= 0 && s->gate <= 0))
+		return AKO_COLOR_YCOCG;
+	return s->color;
+}
+
+akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, size_t channels, size_t image_w,
+                             size_t image_h, size_t batch, void* hip_stream, unsigned flags,
+                             enum akoStatus* out_status)
+{
+	enum akoStatus st = AKO_OK;
+	akoHipPlan* pl = nullptr;
+	g_last_error.clear();
+
+#define PLAN_FAIL(code, msg)      \
+	do                            \
+	{                             \
+		st = (code);              \
+		g_last_error = (msg);     \
+		goto failed;              \
+	} while (0)
+
+	{
+		if (settings == nullptr || batch == 0)
+			PLAN_FAIL(AKO_INVALID_INPUT, "null settings or empty batch");
+		if (channels == 0 || channels > AKO_MAX_CHANNELS)
+			PLAN_FAIL(AKO_INVALID_CHANNELS_NO, "channels must be 1..16");
+		if (image_w == 0 || image_h == 0 || image_w > AKO_MAX_WIDTH || image_h > AKO_MAX_HEIGHT)
+			PLAN_FAIL(AKO_INVALID_DIMENSIONS, "invalid image dimensions");
+		const size_t td = settings->tiles_dimension;
+		if (td != 0 && (td < AKO_MIN_TILES_DIMENSION || td > AKO_MAX_TILES_DIMENSION || (td & (td - 1)) != 0))
+			PLAN_FAIL(AKO_INVALID_TILES_DIMENSIONS, "tiles dimension must be 0 or a power of two >= 8");
+		if ((int)settings->wrap < 0 || (int)settings->wrap > 3)
+			PLAN_FAIL(AKO_INVALID_WRAP_MODE, "invalid wrap mode");
+		if ((int)settings->wavelet < 0 || (int)settings->wavelet > 3)
+			PLAN_FAIL(AKO_INVALID_WAVELET_TRANSFORMATION, "invalid wavelet");
+		if ((int)settings->color < 0 || (int)settings->color > 3)
+			PLAN_FAIL(AKO_INVALID_COLOR_TRANSFORMATION, "invalid colour transformation");
+
+		int ndev = 0;
+		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+		{
+			(void)hipGetLastError();
+			PLAN_FAIL(AKO_ERROR, "no usable HIP device: this library has no CPU fallback");
+		}
+		if (device < 0 || device >= ndev)
+			PLAN_FAIL(AKO_ERROR, "HIP device index out of range");
+		if (hipSetDevice(device) != hipSuccess)
+			PLAN_FAIL(AKO_ERROR, "hipSetDevice failed");
+
+		pl = new akoHipPlan();
+		pl->device = device;
+		pl->stream = (hipStream_t)hip_stream;
+		pl->s = *settings;
+		pl->channels = channels, pl->w = image_w, pl->h = image_h, pl->batch = batch, pl->flags = flags;
+		if (flags & AKO_HIP_PLAN_PLANES_I16)
+			pl->s.color = AKO_COLOR_NONE;
+
+		// tiles in raster order (encode.c:115-204), grouped by extent
+		size_t off = 0;
+		for (size_t ty = 0; ty < image_h; ty += (td ? td : image_h))
+			for (size_t tx = 0; tx < image_w; tx += (td ? td : image_w))
+			{
+				const size_t tw = tile_extent(tx, image_w, td), th = tile_extent(ty, image_h, td);
+				int gi = -1;
+				for (size_t k = 0; k < pl->groups.size(); k++)
+					if (pl->groups[k].tile_w == tw && pl->groups[k].tile_h == th)
+						gi = (int)k;
+				if (gi < 0)
+				{
+					Group g;
+					g.tile_w = (uint32_t)tw, g.tile_h = (uint32_t)th;
+					build_group(g, pl->s, channels);
+					pl->groups.push_back(g);
+					gi = (int)pl->groups.size() - 1;
+				}
+				Group& g = pl->groups[gi];
+				TileDesc d;
+				d.x0 = (uint32_t)tx, d.y0 = (uint32_t)ty, d.stream_off = off;
+				g.tiles.push_back(d);
+				TileInfo ti{tx, ty, tw, th, off * 2, (size_t)g.tile_values * 2, gi};
+				pl->tiles.push_back(ti);
+				off += g.tile_values;
+			}
+		pl->stream_values = off;
+
+		for (Group& g : pl->groups)
+		{
+			if (hipMalloc((void**)&g.d_tiles, g.tiles.size() * sizeof(TileDesc)) != hipSuccess)
+				PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(tile table) failed");
+			if (hipMemcpy(g.d_tiles, g.tiles.data(), g.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice) !=
+			    hipSuccess)
+				PLAN_FAIL(AKO_ERROR, "hipMemcpy(tile table) failed");
+			for (int which = 0; which < 2; which++)
+			{
+				const size_t need = (size_t)scratch_plane_elems(g, which) * channels * g.tiles.size() * batch;
+				if (need > pl->scratch_elems[which])
+					pl->scratch_elems[which] = need;
+			}
+		}
+		for (int which = 0; which < 2; which++)
+			if (pl->scratch_elems[which] != 0 &&
+			    hipMalloc((void**)&pl->scratch[which], pl->scratch_elems[which] * sizeof(int16_t)) != hipSuccess)
+				PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(low-pass scratch) failed");
+	}
+
+	if (out_status)
+		*out_status = AKO_OK;
+	return pl;
+
+failed:
+	(void)hipGetLastError();
+	if (pl)
+		akoHipPlanDestroy(pl);
+	if (out_status)
+		*out_status = st;
+	return nullptr;
+#undef PLAN_FAIL
+}
+
+void akoHipPlanDestroy(akoHipPlan* pl)
+{
+	if (!pl)
+		return;
+	(void)hipSetDevice(pl->device);
+	for (Group& g : pl->groups)
+		if (g.d_tiles)
+			(void)hipFree(g.d_tiles);
+	for (int which = 0; which < 2; which++)
+		if (pl->scratch[which])
+			(void)hipFree(pl->scratch[which]);
+	if (pl->d_img)
+		(void)hipFree(pl->d_img);
+	if (pl->d_stream)
+		(void)hipFree(pl->d_stream);
+	for (int d = 0; d < 2; d++)
+		for (EventPair& e : pl->events[d])
+		{
+			(void)hipEventDestroy(e.a);
+			(void)hipEventDestroy(e.b);
+		}
+	delete pl;
+}
+
+size_t akoHipPlanImageBytes(const akoHipPlan* pl)
+{
+	return pl->w * pl->h * pl->channels * ((pl->flags & AKO_HIP_PLAN_PLANES_I16) ? 2 : 1);
+}
+
+size_t akoHipPlanStreamBytes(const akoHipPlan* pl)
+{
+	return pl->stream_values * 2;
+}
+
+size_t akoHipPlanTiles(const akoHipPlan* pl)
+{
+	return pl->tiles.size();
+}
+
+size_t akoHipPlanBatch(const akoHipPlan* pl)
+{
+	return pl->batch;
+}
+
+int akoHipPlanTileInfo(const akoHipPlan* pl, size_t t, size_t* x, size_t* y, size_t* w, size_t* h, size_t* so,
+                       size_t* sb)
+{
+	if (t >= pl->tiles.size())
+		return fail(AKO_INVALID_INPUT, "tile index out of range%s%s");
+	const TileInfo& ti = pl->tiles[t];
+	if (x) *x = ti.x;
+	if (y) *y = ti.y;
+	if (w) *w = ti.w;
+	if (h) *h = ti.h;
+	if (so) *so = ti.stream_off;
+	if (sb) *sb = ti.stream_bytes;
+	return 0;
+}
+
+int akoHipPlanLevels(const akoHipPlan* pl, size_t t)
+{
+	if (t >= pl->tiles.size())
+		return -1;
+	return (int)pl->groups[pl->tiles[t].group].levels.size();
+}
+
+int akoHipPlanQuant(const akoHipPlan* pl, size_t t, size_t level, size_t channel, int* q, int* g)
+{
+	if (t >= pl->tiles.size())
+		return fail(AKO_INVALID_INPUT, "tile index out of range%s%s");
+	const Group& gr = pl->groups[pl->tiles[t].group];
+	if (level >= gr.levels.size() || channel >= pl->channels)
+		return fail(AKO_INVALID_INPUT, "level / channel out of range%s%s");
+	const int m = (channel == 0) ? 0 : 1;
+	if (q) *q = gr.levels[level].q[m];
+	if (g) *g = gr.levels[level].g[m];
+	return 0;
+}
+
+int akoHipEncode(akoHipPlan* pl, const void* d_images, void* d_streams)
+{
+	if (!pl || !d_images || !d_streams)
+		return fail(AKO_INVALID_INPUT, "null argument%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	return run_encode(pl, d_images, d_streams);
+}
+
+int akoHipDecode(akoHipPlan* pl, const void* d_streams, void* d_images)
+{
+	if (!pl || !d_images || !d_streams)
+		return fail(AKO_INVALID_INPUT, "null argument%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	return run_decode(pl, d_streams, d_images);
+}
+
+int akoHipSynchronize(akoHipPlan* pl)
+{
+	HIP_TRY(hipSetDevice(pl->device));
+	HIP_TRY(hipStreamSynchronize(pl->stream));
+	return 0;
+}
+
+static int ensure_staging(akoHipPlan* pl)
+{
+	if (!pl->d_img)
+		if (hipMalloc(&pl->d_img, akoHipPlanImageBytes(pl) * pl->batch) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(image staging) failed%s%s");
+	if (!pl->d_stream)
+		if (hipMalloc(&pl->d_stream, akoHipPlanStreamBytes(pl) * pl->batch) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(stream staging) failed%s%s");
+	return 0;
+}
+
+int akoHipEncodeHost(akoHipPlan* pl, const void* h_images, void* h_streams)
+{
+	if (!pl || !h_images || !h_streams)
+		return fail(AKO_INVALID_INPUT, "null argument%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	if (int rc = ensure_staging(pl))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(pl->d_img, h_images, akoHipPlanImageBytes(pl) * pl->batch, hipMemcpyHostToDevice,
+	                       pl->stream));
+	if (int rc = akoHipEncode(pl, pl->d_img, pl->d_stream))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(h_streams, pl->d_stream, akoHipPlanStreamBytes(pl) * pl->batch, hipMemcpyDeviceToHost,
+	                       pl->stream));
+	HIP_TRY(hipStreamSynchronize(pl->stream));
+	return 0;
+}
+
+int akoHipDecodeHost(akoHipPlan* pl, const void* h_streams, void* h_images)
+{
+	if (!pl || !h_images || !h_streams)
+		return fail(AKO_INVALID_INPUT, "null argument%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	if (int rc = ensure_staging(pl))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(pl->d_stream, h_streams, akoHipPlanStreamBytes(pl) * pl->batch, hipMemcpyHostToDevice,
+	                       pl->stream));
+	if (int rc = akoHipDecode(pl, pl->d_stream, pl->d_img))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(h_images, pl->d_img, akoHipPlanImageBytes(pl) * pl->batch, hipMemcpyDeviceToHost,
+	                       pl->stream));
+	HIP_TRY(hipStreamSynchronize(pl->stream));
+	return 0;
+}
+
+int akoHipPlanSetProfiling(akoHipPlan* pl, int enabled)
+{
+	pl->profiling = enabled != 0;
+	pl->pending[0].clear();
+	pl->pending[1].clear();
+	pl->events_used[0] = pl->events_used[1] = 0;
+	return 0;
+}
+
+size_t akoHipPlanKernelRecords(akoHipPlan* pl, int decode, struct akoHipKernelRecord* out, size_t capacity)
+{
+	const int d = decode ? 1 : 0;
+	const auto& v = pl->pending[d];
+	size_t n = 0;
+	for (const auto& p : v)
+	{
+		if (n == capacity)
+			break;
+		out[n] = p.rec;
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, pl->events[d][p.ev].a, pl->events[d][p.ev].b) != hipSuccess)
+		{
+			(void)hipGetLastError();
+			ms = -1.f;
+		}
+		out[n].ms = ms;
+		n++;
+	}
+	return n;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

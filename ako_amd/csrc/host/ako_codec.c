@@ -1,0 +1,344 @@
+/*
+ * ako_codec.c -- akoEncodeExt / akoDecodeExt: the per image drivers behind the public API
+ * (reference: library/encode.c:38-232, library/decode.c:38-250).
+ *
+ * Same validation order, status codes, ownership rules and event sequence as the reference, but
+ * the tile loop's two transform calls (akoFormatToPlanarI16Yuv + akoLift, akoUnlift +
+ * akoFormatToInterleavedU8Rgb) are replaced by ONE batched device call for all tiles of the image
+ * through the C-ABI of include/ako_hip.h.  The host then walks the tiles in raster order for the
+ * entropy stage and the blob assembly.
+ *
+ * Events: the reference fires FORMAT, WAVELET and COMPRESSION start/end pairs per tile, in tile
+ * order, on the caller's thread (encode.c:132-184, decode.c:145-207; consumers such as
+ * tools/benchmark.hpp:73-89 reset on tile 0 and print on the last tile).  That sequence is kept;
+ * the whole device transform runs inside tile 0's WAVELET bracket (encode) or the last
+ * tile's WAVELET bracket (decode), because it cannot start before every tile is decompressed.
+ *
+ * Device selection: environment variable AKO_HIP_DEVICE (default 0).  No CPU fallback.
+ */
+#include "ako_host.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void fire(const struct akoCallbacks* c, size_t tile, size_t total, enum akoEvent e)
+{
+	if (c->events != NULL)
+		c->events(tile, total, e, c->events_data);
+}
+
+static int chosen_device(void)
+{
+	const char* e = getenv("AKO_HIP_DEVICE");
+	return (e != NULL && *e != '\0') ? atoi(e) : 0;
+}
+
+static void complain(const char* where)
+{
+	/* failing loudly: a missing / broken HIP path must never pass for a working codec */
+	if (getenv("AKO_HIP_QUIET") == NULL)
+		fprintf(stderr, "libako (HIP): %s: %s\n", where, akoHipLastError());
+}
+
+AKO_API size_t akoEncodeExt(const struct akoCallbacks* c, const struct akoSettings* s, size_t channels,
+                            size_t image_w, size_t image_h, const void* in, void** out, enum akoStatus* out_status)
+{
+	enum akoStatus status = AKO_OK;
+	uint8_t* blob = NULL;
+	size_t blob_size = 0;
+	uint8_t* streams = NULL;
+	uint8_t* packed = NULL;
+	akoHipPlan* plan = NULL;
+
+	const struct akoCallbacks cb = (c != NULL) ? *c : akoDefaultCallbacks();
+	struct akoSettings st = (s != NULL) ? *s : akoDefaultSettings();
+
+	if (cb.malloc == NULL || cb.realloc == NULL || cb.free == NULL)
+	{
+		status = AKO_INVALID_CALLBACKS;
+		goto failure;
+	}
+
+	st.color = akoHipEffectiveColor(&st); /* encode.c:59-64 */
+
+	if (in == NULL)
+	{
+		status = AKO_INVALID_INPUT;
+		goto failure;
+	}
+
+	blob_size = sizeof(struct akoHead);
+	if ((blob = cb.malloc(blob_size)) == NULL)
+	{
+		status = AKO_NO_ENOUGH_MEMORY;
+		goto failure;
+	}
+	if ((status = akoHostHeadWrite(channels, image_w, image_h, &st, blob)) != AKO_OK)
+		goto failure;
+
+	if ((plan = akoHipPlanCreate(chosen_device(), &st, channels, image_w, image_h, 1, NULL, 0, &status)) == NULL)
+	{
+		complain("akoEncodeExt");
+		goto failure;
+	}
+
+	const size_t tiles = akoHipPlanTiles(plan);
+	const size_t stream_bytes = akoHipPlanStreamBytes(plan);
+	if ((streams = cb.malloc(stream_bytes)) == NULL)
+	{
+		status = AKO_NO_ENOUGH_MEMORY;
+		goto failure;
+	}
+
+	size_t max_tile_bytes = 0;
+	for (size_t t = 0; t < tiles; t++)
+	{
+		size_t bytes = 0;
+		akoHipPlanTileInfo(plan, t, NULL, NULL, NULL, NULL, NULL, &bytes);
+		if (bytes > max_tile_bytes)
+			max_tile_bytes = bytes;
+	}
+	if (st.compression != AKO_COMPRESSION_NONE && (packed = cb.malloc(max_tile_bytes + 8)) == NULL)
+	{
+		status = AKO_NO_ENOUGH_MEMORY;
+		goto failure;
+	}
+	if (st.compression == AKO_COMPRESSION_NONE)
+	{
+		/* final size is known up front: one allocation instead of one realloc per tile */
+		uint8_t* grown = cb.realloc(blob, blob_size + stream_bytes);
+		if (grown == NULL)
+		{
+			status = AKO_NO_ENOUGH_MEMORY;
+			goto failure;
+		}
+		blob = grown;
+	}
+
+	for (size_t t = 0; t < tiles; t++)
+	{
+		size_t off = 0, bytes = 0;
+		akoHipPlanTileInfo(plan, t, NULL, NULL, NULL, NULL, &off, &bytes);
+
+		fire(&cb, t, tiles, AKO_EVENT_FORMAT_START);
+		fire(&cb, t, tiles, AKO_EVENT_FORMAT_END);
+
+		if (st.wavelet != AKO_WAVELET_NONE || t == 0)
+		{
+			if (st.wavelet != AKO_WAVELET_NONE)
+				fire(&cb, t, tiles, AKO_EVENT_WAVELET_START);
+			if (t == 0)
+			{
+				const int rc = akoHipEncodeHost(plan, in, streams);
+				if (rc != 0)
+				{
+					status = (enum akoStatus)rc;
+					complain("akoEncodeExt");
+					goto failure;
+				}
+			}
+			if (st.wavelet != AKO_WAVELET_NONE)
+				fire(&cb, t, tiles, AKO_EVENT_WAVELET_END);
+		}
+
+		fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_START);
+		if (st.compression != AKO_COMPRESSION_NONE)
+		{
+			/* compression.c:36-55: output capacity == input size, uint32 block size in front */
+			const size_t payload = akoHostKagariEncode(bytes, bytes - 4, streams + off, packed + 4);
+			if (payload == 0)
+			{
+				status = AKO_ERROR; /* tile did not shrink: encode.c:159-164 */
+				goto failure;
+			}
+			const uint32_t p32 = (uint32_t)payload;
+			memcpy(packed, &p32, 4);
+
+			uint8_t* grown = cb.realloc(blob, blob_size + payload + 4);
+			if (grown == NULL)
+			{
+				status = AKO_NO_ENOUGH_MEMORY;
+				goto failure;
+			}
+			blob = grown;
+			memcpy(blob + blob_size, packed, payload + 4);
+			blob_size += payload + 4;
+		}
+		else
+		{
+			memcpy(blob + blob_size, streams + off, bytes);
+			blob_size += bytes;
+		}
+		fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_END);
+	}
+
+	akoHipPlanDestroy(plan);
+	cb.free(streams);
+	if (packed != NULL)
+		cb.free(packed);
+
+	if (out_status != NULL)
+		*out_status = AKO_OK;
+	if (out != NULL)
+		*out = blob;
+	else
+		cb.free(blob); /* caller only wanted the size: encode.c:214-217 */
+	return blob_size;
+
+failure:
+	if (plan != NULL)
+		akoHipPlanDestroy(plan);
+	if (cb.free != NULL)
+	{
+		if (streams != NULL)
+			cb.free(streams);
+		if (packed != NULL)
+			cb.free(packed);
+		if (blob != NULL)
+			cb.free(blob);
+	}
+	if (out_status != NULL)
+		*out_status = status;
+	return 0;
+}
+
+AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, const void* input,
+                              struct akoSettings* out_s, size_t* out_channels, size_t* out_w, size_t* out_h,
+                              enum akoStatus* out_status)
+{
+	enum akoStatus status = AKO_OK;
+	struct akoSettings st;
+	memset(&st, 0, sizeof st);
+	size_t channels = 0, image_w = 0, image_h = 0;
+	uint8_t* image = NULL;
+	uint8_t* streams = NULL;
+	akoHipPlan* plan = NULL;
+
+	const struct akoCallbacks cb = (c != NULL) ? *c : akoDefaultCallbacks();
+	if (cb.malloc == NULL || cb.realloc == NULL || cb.free == NULL)
+	{
+		status = AKO_INVALID_CALLBACKS;
+		goto failure;
+	}
+	if (input == NULL)
+	{
+		status = AKO_INVALID_INPUT;
+		goto failure;
+	}
+	if (input_size < sizeof(struct akoHead))
+	{
+		/* the reference's own bound check here is vacuous (decode.c:71); a short blob must not be read */
+		status = AKO_BROKEN_INPUT;
+		goto failure;
+	}
+	if ((status = akoHostHeadRead(input, &channels, &image_w, &image_h, &st)) != AKO_OK)
+		goto failure;
+
+	if ((plan = akoHipPlanCreate(chosen_device(), &st, channels, image_w, image_h, 1, NULL, 0, &status)) == NULL)
+	{
+		complain("akoDecodeExt");
+		goto failure;
+	}
+
+	const size_t tiles = akoHipPlanTiles(plan);
+	const size_t stream_bytes = akoHipPlanStreamBytes(plan);
+	image = cb.malloc(image_w * image_h * channels);
+	streams = cb.malloc(stream_bytes);
+	if (image == NULL || streams == NULL)
+	{
+		status = AKO_NO_ENOUGH_MEMORY;
+		goto failure;
+	}
+
+	const uint8_t* cursor = (const uint8_t*)input + sizeof(struct akoHead);
+	const uint8_t* const end = (const uint8_t*)input + input_size;
+
+	for (size_t t = 0; t < tiles; t++)
+	{
+		size_t off = 0, bytes = 0;
+		akoHipPlanTileInfo(plan, t, NULL, NULL, NULL, NULL, &off, &bytes);
+
+		fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_START);
+		if (st.compression != AKO_COMPRESSION_NONE)
+		{
+			uint32_t block = 0;
+			if ((size_t)(end - cursor) < 4)
+			{
+				status = AKO_BROKEN_INPUT;
+				goto failure;
+			}
+			memcpy(&block, cursor, 4);
+			if ((size_t)(end - cursor) - 4 < block)
+			{
+				status = AKO_BROKEN_INPUT;
+				goto failure;
+			}
+			const size_t used = akoHostKagariDecode(bytes / 2, block, bytes, cursor + 4, streams + off);
+			if (used == 0 || used != block) /* compression.c:69-70 */
+			{
+				status = AKO_BROKEN_INPUT;
+				goto failure;
+			}
+			cursor += (size_t)block + 4;
+		}
+		else
+		{
+			if ((size_t)(end - cursor) < bytes) /* decode.c:163-167 */
+			{
+				status = AKO_BROKEN_INPUT;
+				goto failure;
+			}
+			memcpy(streams + off, cursor, bytes);
+			cursor += bytes;
+		}
+		fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_END);
+
+		if (st.wavelet != AKO_WAVELET_NONE)
+			fire(&cb, t, tiles, AKO_EVENT_WAVELET_START);
+		if (t + 1 == tiles)
+		{
+			const int rc = akoHipDecodeHost(plan, streams, image);
+			if (rc != 0)
+			{
+				status = (enum akoStatus)rc;
+				complain("akoDecodeExt");
+				goto failure;
+			}
+		}
+		if (st.wavelet != AKO_WAVELET_NONE)
+			fire(&cb, t, tiles, AKO_EVENT_WAVELET_END);
+
+		fire(&cb, t, tiles, AKO_EVENT_FORMAT_START);
+		fire(&cb, t, tiles, AKO_EVENT_FORMAT_END);
+	}
+
+	akoHipPlanDestroy(plan);
+	cb.free(streams);
+
+	if (out_s != NULL)
+		*out_s = st;
+	if (out_channels != NULL)
+		*out_channels = channels;
+	if (out_w != NULL)
+		*out_w = image_w;
+	if (out_h != NULL)
+		*out_h = image_h;
+	if (out_status != NULL)
+		*out_status = AKO_OK;
+	return image;
+
+failure:
+	if (plan != NULL)
+		akoHipPlanDestroy(plan);
+	if (cb.free != NULL)
+	{
+		if (streams != NULL)
+			cb.free(streams);
+		if (image != NULL)
+			cb.free(image);
+	}
+	if (out_status != NULL)
+		*out_status = status;
+	return NULL;
+}

@@ -1,0 +1,32 @@
+/*
+ * ako_host.h -- internal declarations of the host (C11) side of libako.
+ *
+ * The host keeps what the reference keeps on the CPU besides the transform: the 16 byte header
+ * (reference: library/head.c), the Kagari entropy coder (library/kagari.c, library/compression.c),
+ * the float quantizer curve (library/quantization.c) and the per image drivers
+ * (library/encode.c, library/decode.c).  The transform itself is reached ONLY through the device
+ * C-ABI of include/ako_hip.h -- there is no CPU implementation of it in this library.
+ */
+#ifndef AKO_HOST_H
+#define AKO_HOST_H
+
+#include "../../../include/ako.h"
+#include "../../../include/ako_hip.h"
+
+#define AKO_API __attribute__((visibility("default")))
+
+/* ako_quant.c */
+AKO_API int16_t akoHostQuantStep(int factor, int mul, size_t tile_w, size_t tile_h, size_t cur_w, size_t cur_h);
+AKO_API int16_t akoHostGateStep(int factor, int mul, size_t tile_w, size_t tile_h, size_t cur_w, size_t cur_h);
+
+/* ako_head.c */
+AKO_API enum akoStatus akoHostHeadWrite(size_t channels, size_t w, size_t h, const struct akoSettings* s, void* out16);
+AKO_API enum akoStatus akoHostHeadRead(const void* in16, size_t* channels, size_t* w, size_t* h,
+                                       struct akoSettings* out_s);
+
+/* ako_kagari.c: block = uint32 payload size + payload (reference: library/compression.c:30-73) */
+AKO_API size_t akoHostKagariEncode(size_t input_bytes, size_t output_capacity, const void* input, void* output);
+AKO_API size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_bytes, const void* input,
+                                   void* output);
+
+#endif

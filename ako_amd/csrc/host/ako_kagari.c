@@ -1,0 +1,200 @@
+/*
+ * ako_kagari.c -- host entropy stage "Kagari" (reference: library/kagari.c:59-366).
+ *
+ * Stays on the host by design (BASELINE north star); the GPU hands over the raw coefficient
+ * stream and this file turns it into the bit-stream the reference writes:
+ *
+ *   - every int16 coefficient c is sent as the Elias-gamma code of zigzag(c) + 1
+ *     (kagari.c:169-173,214-217): L zero bits, then the L+1 significant bits, MSB first
+ *   - a value repeated more than twice is followed, when the run ends, by the gamma code of
+ *     (repeats - 2) + 1; a run counter reaching 65534 is flushed early and restarts
+ *     (kagari.c:34,194-198,254-283)
+ *
+ * The encoder below is organised around maximal RUNS of equal values rather than the reference's
+ * per-value state machine; the bit-stream and the "does it still fit" failure rule (capacity is
+ * checked whenever whole bytes leave the 64 bit accumulator: kagari.c:64-78,91-112) are the same.
+ */
+#include "ako_host.h"
+
+#include <string.h>
+
+#define RUN_LIMIT 65534u /* AKO_ELIAS_MAX - 1 */
+
+struct bit_sink
+{
+	uint64_t acc;
+	int pending; /* valid low bits of acc */
+	uint8_t* at;
+	const uint8_t* limit;
+};
+
+static inline int gamma_bits(uint16_t v)
+{
+	int extra = 0;
+	while (v > 1)
+	{
+		v >>= 1;
+		extra++;
+	}
+	return 2 * extra + 1;
+}
+
+/* returns 0 when the output is exhausted */
+static inline int sink_put(struct bit_sink* s, uint16_t code)
+{
+	const int bits = gamma_bits(code);
+	if (s->pending > 8 && s->pending + bits > 64)
+	{
+		if (s->at + (s->pending / 8) >= s->limit)
+			return 0;
+		while (s->pending + bits > 64)
+		{
+			s->pending -= 8;
+			*s->at++ = (uint8_t)(s->acc >> s->pending);
+		}
+	}
+	s->acc = (s->acc << bits) | code;
+	s->pending += bits;
+	return 1;
+}
+
+static inline uint16_t value_code(int16_t c)
+{
+	const uint16_t zz = (uint16_t)(((int)c << 1) ^ ((int)c >> 15));
+	return (uint16_t)(zz + 1);
+}
+
+size_t akoHostKagariEncode(size_t input_bytes, size_t capacity, const void* input, void* output)
+{
+	if (capacity == 0 || input_bytes == 0 || (input_bytes & 1) != 0)
+		return 0;
+
+	const int16_t* in = input;
+	const size_t n = input_bytes / 2;
+	struct bit_sink s = {0, 0, output, (const uint8_t*)output + capacity};
+
+	size_t i = 0;
+	while (i < n)
+	{
+		const int16_t v = in[i++];
+		const uint16_t code = value_code(v);
+		if (!sink_put(&s, code))
+			return 0;
+
+		/* repeats of v that follow */
+		size_t repeats = 0;
+		while (i + repeats < n && in[i + repeats] == v)
+			repeats++;
+		i += repeats;
+
+		while (repeats != 0)
+		{
+			const size_t chunk = repeats < RUN_LIMIT ? repeats : RUN_LIMIT;
+			const size_t literal = chunk < 2 ? chunk : 2;
+			for (size_t k = 0; k < literal; k++)
+				if (!sink_put(&s, code))
+					return 0;
+			if (chunk >= 2 && !sink_put(&s, (uint16_t)(chunk - 2 + 1)))
+				return 0;
+			repeats -= chunk;
+		}
+	}
+
+	/* drain: whole bytes, then the zero padded tail (kagari.c:91-112) */
+	while (s.pending >= 8)
+	{
+		if (s.at + 1 >= s.limit)
+			return 0;
+		s.pending -= 8;
+		*s.at++ = (uint8_t)(s.acc >> s.pending);
+	}
+	if (s.pending != 0)
+	{
+		if (s.at + 1 >= s.limit)
+			return 0;
+		*s.at++ = (uint8_t)(s.acc << (8 - s.pending));
+	}
+	return (size_t)(s.at - (uint8_t*)output);
+}
+
+/* ---- decoder ------------------------------------------------------------------------------- */
+
+struct bit_source
+{
+	const uint8_t* base;
+	size_t bytes;
+	size_t bitpos;
+};
+
+/* next 32 bits at bitpos, zero padded past the end */
+static inline uint32_t source_peek(const struct bit_source* s)
+{
+	const size_t byte = s->bitpos >> 3;
+	uint64_t w = 0;
+	for (size_t k = 0; k < 5; k++)
+		w = (w << 8) | ((byte + k < s->bytes) ? s->base[byte + k] : 0);
+	return (uint32_t)(w >> (8 - (s->bitpos & 7)));
+}
+
+/* gamma code -> value (1..65535), or 0 on a broken stream */
+static inline uint32_t source_get(struct bit_source* s)
+{
+	const uint32_t w = source_peek(s);
+	if (w == 0)
+		return 0;
+	const int zeros = __builtin_clz(w);
+	if (zeros > 15)
+		return 0;
+	const int bits = 2 * zeros + 1;
+	if (s->bitpos + (size_t)bits > s->bytes * 8)
+		return 0;
+	s->bitpos += (size_t)bits;
+	return w >> (32 - bits);
+}
+
+size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_bytes, const void* input, void* output)
+{
+	if (output_bytes == 0 || input_bytes == 0 || values_no == 0 || (output_bytes & 1) != 0)
+		return 0;
+	if (values_no > output_bytes / 2)
+		return 0;
+
+	struct bit_source s = {input, input_bytes, 0};
+	int16_t* out = output;
+	size_t done = 0;
+	int16_t prev = 0;
+	unsigned same = 0; /* repeats of prev seen since the last run code */
+
+	while (done < values_no)
+	{
+		const uint32_t code = source_get(&s);
+		if (code == 0)
+			return 0;
+		const uint16_t zz = (uint16_t)(code - 1);
+		const int16_t v = (int16_t)((zz >> 1) ^ (uint16_t)(~(zz & 1) + 1)); /* kagari.c:175-178 */
+		out[done++] = v;
+
+		if (done > 1 && v == prev)
+		{
+			if (++same == 2)
+			{
+				const uint32_t run = source_get(&s);
+				if (run == 0)
+					return 0;
+				const size_t extra = run - 1;
+				if (extra > values_no - done)
+					return 0;
+				for (size_t k = 0; k < extra; k++)
+					out[done + k] = prev;
+				done += extra;
+				same = 0;
+			}
+		}
+		else
+		{
+			prev = v;
+			same = 0;
+		}
+	}
+	return (s.bitpos + 7) / 8;
+}

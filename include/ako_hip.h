@@ -89,7 +89,9 @@ int akoHipDecodeHost(akoHipPlan*, const void* h_streams, void* h_images);
 /*
  * Per-kernel timing for roofline reporting.  With profiling on, every kernel launch of
  * akoHipEncode / akoHipDecode is bracketed by hipEvents on the plan's stream; after
- * akoHipSynchronize the records of the LAST encode and decode calls can be read back.
+ * akoHipSynchronize the records of ALL encode (decode = 0) or decode (decode = 1) launches since
+ * profiling was last switched on can be read back, in launch order.  akoHipPlanSetProfiling
+ * (either value) forgets the records collected so far.
  */
 struct akoHipKernelRecord
 {

@@ -1,0 +1,204 @@
+"""CPU: the C-ABI library loads, exports every symbol include/*.h declares, and its HOST logic
+(header, quantizer curve, Kagari) agrees with the oracle and the golden vectors.  No GPU compute here.
+"""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+from ako_amd import api
+
+
+def _declared_symbols():
+    names = set()
+    for header in ("ako.h", "ako_hip.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\b(ako[A-Z]\w*)\s*\(", text):
+            names.add(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.lib()
+    names = _declared_symbols()
+    assert {"akoEncodeExt", "akoDecodeExt", "akoDefaultSettings", "akoDefaultCallbacks", "akoDefaultFree",
+            "akoStatusString", "akoVersionMajor", "akoVersionMinor", "akoVersionPatch", "akoFormatVersion",
+            "akoHipPlanCreate", "akoHipEncode", "akoHipDecode"} <= names
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/ but not exported by libako.so"
+
+
+def test_defaults_and_strings():
+    s = api.default_settings()   # library/misc.c:30-47
+    assert (s.wavelet, s.color, s.wrap, s.compression, s.tiles_dimension) == (0, 0, 0, 0, 0)
+    assert (s.quantization, s.gate, s.chroma_loss, s.discard_non_visible) == (16, 0, 1, 0)
+    L = api.lib()
+    assert (L.akoVersionMajor(), L.akoVersionMinor(), L.akoVersionPatch(), L.akoFormatVersion()) == (0, 2, 0, 2)
+    assert api.status_string(0) == "Everything Ok!"
+    assert api.status_string(15) == "Broken input/premature end"
+    assert api.status_string(99) == "Unknown status code"
+    assert C.sizeof(api.Settings) == 40 and C.sizeof(api.Callbacks) == 40
+
+
+def test_effective_color_rule():
+    L = api.lib()
+    for color in range(4):
+        for q in (0, 16):
+            for g in (0, 5):
+                s = api.settings(color=color, q=q, g=g)
+                exp = color
+                if color == 0 and (q > 0 or g > 0):
+                    exp = 3
+                if color == 3 and q <= 0 and g <= 0:
+                    exp = 0
+                assert L.akoHipEffectiveColor(C.byref(s)) == exp
+
+
+def test_quant_curve_matches_golden_and_oracle(po):
+    L = api.lib()
+    q = json.load(open(os.path.join(GOLDEN, "quant.json")))
+    for key, rows in q.items():
+        tw, th = (int(v) for v in key.split("x"))
+        for factor, w, h, q1, q2, g1, g2 in rows:
+            assert L.akoHostQuantStep(factor, 1, tw, th, w, h) == q1
+            assert L.akoHostQuantStep(factor, 2, tw, th, w, h) == q2
+            assert L.akoHostGateStep(factor, 1, tw, th, w, h) == g1
+            assert L.akoHostGateStep(factor, 2, tw, th, w, h) == g2
+    rng = np.random.default_rng(1)
+    O = po.lib()
+    for _ in range(500):
+        tw, th = int(rng.integers(3, 20000)), int(rng.integers(3, 20000))
+        f, m = int(rng.choice([0, 1, 7, 16, 100, 8192])), int(rng.choice([1, 2, 5]))
+        w, h = tw, th
+        while w > 2 and h > 2:
+            assert L.akoHostQuantStep(f, m, tw, th, w, h) == O.orcQuantStep(f, m, tw, th, w, h)
+            assert L.akoHostGateStep(f, m, tw, th, w, h) == O.orcGateStep(f, m, tw, th, w, h)
+            w, h = (w + 1) // 2, (h + 1) // 2
+
+
+def test_float_quantizer_is_exact_truncating_division():
+    """The kernels quantize with trunc(float(x) * rq), rq = float((1/q)(1 + 1e-6)) (ako_kernels.hip.h:quantize).
+    Sweep every q and, for each, every multiple of q and its neighbours (the only places where
+    rounding could cross an integer) plus random values, in IEEE float32 as the GPU does."""
+    qs = np.arange(1, 32766, dtype=np.int64)
+    rng = np.random.default_rng(0)
+    for q in qs[::1]:
+        rq = np.float32((1.0 / float(q)) * (1.0 + 1e-6))
+        k = np.arange(0, 32768 // q + 1, dtype=np.int64) * q
+        x = np.unique(np.clip(np.concatenate([k - 1, k, k + 1, rng.integers(-32768, 32768, 16)]), -32768, 32767))
+        x = np.concatenate([x, -x[x > -32768 + 1]])
+        x = np.clip(x, -32768, 32767)
+        got = np.trunc(x.astype(np.float32) * rq).astype(np.int64)
+        exp = np.sign(x) * (np.abs(x) // q)
+        assert np.array_equal(got, exp), int(q)
+
+
+def test_head_bytes_and_validation(po):
+    L = api.lib()
+    O = po.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        s = api.settings(wavelet=int(rng.integers(0, 5)), color=int(rng.integers(0, 5)), wrap=int(rng.integers(0, 5)),
+                         compression=int(rng.integers(0, 4)),
+                         tiles=int(rng.choice([0, 0, 4, 8, 12, 64, 512, 1024, 4096])))
+        ch, w, h = int(rng.integers(1, 18)), int(rng.integers(0, 5000)), int(rng.integers(0, 5000))
+        a, b = np.zeros(16, np.uint8), np.zeros(16, np.uint8)
+        os_ = po.Settings(s.wavelet, s.color, s.wrap, s.compression, s.tiles_dimension, 16, 0, 1, 0)
+        ra = L.akoHostHeadWrite(ch, w, h, C.byref(s), a.ctypes.data_as(C.c_void_p))
+        rb = O.orcHeadWrite(ch, w, h, C.byref(os_), b.ctypes.data_as(C.c_void_p))
+        assert ra == rb
+        if ra == 0:
+            assert np.array_equal(a, b)
+            s2 = api.Settings()
+            c2, w2, h2 = C.c_size_t(), C.c_size_t(), C.c_size_t()
+            r = L.akoHostHeadRead(a.ctypes.data_as(C.c_void_p), C.byref(c2), C.byref(w2), C.byref(h2), C.byref(s2))
+            if s.tiles_dimension >= 1024:
+                assert r == 14   # AKO_INVALID_FLAGS: the reference's reader quirk (head.c:124)
+            else:
+                assert r == 0 and (c2.value, w2.value, h2.value) == (ch, w, h)
+                assert (s2.wavelet, s2.color, s2.wrap, s2.compression, s2.tiles_dimension) == (
+                    s.wavelet, s.color, s.wrap, s.compression, s.tiles_dimension)
+
+
+def test_kagari_matches_oracle_bit_for_bit(po):
+    L, O = api.lib(), po.lib()
+    rng = np.random.default_rng(4)
+    V = C.c_void_p
+    cases = []
+    for _ in range(200):
+        n = int(rng.integers(1, 6000))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            v = rng.integers(-5, 6, n, dtype=np.int16)
+        elif kind == 1:
+            v = np.repeat(rng.integers(-300, 300, n // 7 + 1, dtype=np.int16), 7)[:n].copy()
+        elif kind == 2:
+            v = np.zeros(n, np.int16)
+            v[::max(1, n // 5)] = 77
+        else:
+            v = rng.integers(-32768, 32768, n, dtype=np.int16)
+        cases.append(v)
+    long_run = np.zeros(200000, np.int16)
+    long_run[150000:] = 3
+    cases.append(long_run)
+    cases.append(np.full(65534 * 2 + 5, -7, np.int16))
+    for v in cases:
+        n = v.size
+        for cap in (n * 2 + 64, max(2, n), max(2, n // 2)):
+            o1, o2 = np.zeros(cap + 8, np.uint8), np.zeros(cap + 8, np.uint8)
+            a = L.akoHostKagariEncode(n * 2, cap, v.ctypes.data_as(V), o1.ctypes.data_as(V))
+            b = O.orcKagariEncode(n * 2, cap, v.ctypes.data_as(V), o2.ctypes.data_as(V))
+            assert a == b, (n, cap)
+            if a:
+                assert np.array_equal(o1[:a], o2[:a])
+                d = np.zeros(n, np.int16)
+                assert L.akoHostKagariDecode(n, a, n * 2, o1.ctypes.data_as(V), d.ctypes.data_as(V)) == a
+                assert np.array_equal(d, v)
+    # truncated / corrupt payloads must be refused, not crash
+    v = rng.integers(-50, 50, 1000, dtype=np.int16)
+    o = np.zeros(4096, np.uint8)
+    a = L.akoHostKagariEncode(2000, 4096, v.ctypes.data_as(V), o.ctypes.data_as(V))
+    d = np.zeros(1000, np.int16)
+    assert L.akoHostKagariDecode(1000, a // 2, 2000, o.ctypes.data_as(V), d.ctypes.data_as(V)) == 0
+
+
+def test_kagari_golden_file_payload(po, golden_sums):
+    """The reference's .ako for BASELINE configs[0]: re-compress the oracle's raw stream with the
+    product's host coder and compare with the golden file checksum."""
+    exp = golden_sums["kagari"]["cfg0_512_cdf53_q16"]
+    img = po.gen_image(0, 512, 512)
+    s = po.settings(wavelet=1, q=16, g=0, compression=2)
+    raw, _ = po.encode_image(s, img)
+    body = raw[16:]
+    L = api.lib()
+    out = np.zeros(body.size, np.uint8)
+    n = L.akoHostKagariEncode(body.size, body.size - 4, body.ctypes.data_as(C.c_void_p),
+                              out[4:].ctypes.data_as(C.c_void_p))
+    assert n + 4 + 16 == exp["blob"]["bytes"]
+    head = raw[:16].copy()
+    head[13] = int(head[13]) & 0xF3            # compression field (flag bits 10-11) := KAGARI (0)
+    blob = np.concatenate([head, np.frombuffer(np.uint32(n).tobytes(), np.uint8), out[4:4 + n]])
+    assert f"{po.adler32(blob):08x}" == exp["blob"]["adler32"]
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: covered by the gpu tests")
+def test_no_gpu_fails_loudly_not_silently():
+    """Without a HIP device the product path must refuse to work (no CPU fallback)."""
+    os.environ["AKO_HIP_QUIET"] = "1"
+    img = np.zeros((16, 16, 4), np.uint8)
+    with pytest.raises(api.AkoError) as e:
+        api.encode(img)
+    assert e.value.status == api.AKO_ERROR and "no usable HIP device" in str(e.value)
+    # validation still happens before the device is touched, in the reference's order
+    with pytest.raises(api.AkoError) as e:
+        api.encode(img, api.settings(tiles=12))
+    assert e.value.status == 4
+    with pytest.raises(api.AkoError) as e:
+        api.decode(np.zeros(64, np.uint8))
+    assert e.value.status == 11
