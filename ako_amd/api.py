@@ -84,6 +84,14 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m ako_amd.build` "
                           "(there is no CPU fallback for the transform path)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Whichever HIP
+    # runtime is loaded FIRST serves the whole process (same sonames); if the system runtime that
+    # libako.so links against comes first, torch afterwards reports "No HIP GPUs are available".
+    # So make sure torch's copy is in before libako.so is opened.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz = C.c_void_p, C.c_size_t
     L.akoEncodeExt.restype = sz
