@@ -6,11 +6,13 @@
 // and the float quantizer / gate scalars (library/quantization.c:43-98) are prepared once per plan
 // on the host.
 #include "ako_kernels.hip.h"
+#include "ako_stream.hip.h"
 
 #include "../../include/ako_hip.h"
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -253,6 +255,81 @@ void launch_inverse(int kind, const LevelParams& P, uint32_t blocks, size_t smem
 	}
 }
 
+// ---- choice between the window engine and the register-streaming kernels ----------------------
+enum { PATH_AUTO = 0, PATH_GENERIC = 1, PATH_STREAM = 2 };
+
+int path_mode()
+{
+	const char* e = getenv("AKO_HIP_PATH");
+	if (e == nullptr)
+		return PATH_AUTO;
+	if (strcmp(e, "generic") == 0)
+		return PATH_GENERIC;
+	if (strcmp(e, "stream") == 0)
+		return PATH_STREAM;
+	return PATH_AUTO;
+}
+
+// streaming kernels need an even level width (no phantom column) of at least 8 samples;
+// in AUTO mode they are used where they pay: wide levels
+bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
+{
+	const int mode = path_mode();
+	if (mode == PATH_GENERIC)
+		return false;
+	if ((L.cw & 1) != 0 || L.cw < 8 || L.tw < 4 || L.th < 2)
+		return false;
+	if (u8 && pl->channels != 4)
+		return false;
+	if (mode == PATH_STREAM)
+		return true;
+	return L.tw >= 64 && L.th >= 32;
+}
+
+StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
+{
+	StreamGeom G;
+	G.strips = (L.tw + SNET - 1) / SNET;
+	uint32_t seg_rows = 0;
+	if (const char* e = getenv("AKO_HIP_SEG_ROWS"))
+		seg_rows = (uint32_t)atoi(e);
+	if (seg_rows == 0)
+	{
+		// aim at ~8192 waves per launch (256 CUs x 8 waves x 4 rounds); 6 halo slots per segment
+		const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
+		uint64_t segs = (8192 + per_seg - 1) / per_seg;
+		if (segs < 1)
+			segs = 1;
+		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
+		if (seg_rows < 32)
+			seg_rows = 32;
+	}
+	if (seg_rows > L.th)
+		seg_rows = L.th;
+	G.seg_rows = seg_rows;
+	G.segs = (L.th + seg_rows - 1) / seg_rows;
+	return G;
+}
+
+template <int NPL, bool U8>
+void launch_forward_stream(int kind, bool narrow, const LevelParams& P, const StreamGeom& G, uint32_t blocks,
+                           hipStream_t st)
+{
+#define AKO_FS(K, N)                                                                                         \
+	hipLaunchKernelGGL((k_forward_stream<K, NPL, U8, N>), dim3(blocks), dim3(THREADS), 0, st, P, G)
+	if (kind == K_DD137)
+	{
+		if (narrow) AKO_FS(K_DD137, true); else AKO_FS(K_DD137, false);
+	}
+	else if (kind == K_CDF53)
+	{
+		if (narrow) AKO_FS(K_CDF53, true); else AKO_FS(K_CDF53, false);
+	}
+	else
+		AKO_FS(K_HAAR, true);
+#undef AKO_FS
+}
+
 int check_blocks(uint64_t blocks)
 {
 	if (blocks == 0 || blocks > 0x7FFFFFFFull)
@@ -357,19 +434,43 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				P.dst_inst_stride = P.dst_plane_stride * pl->channels;
 			}
 
-			const uint64_t blocks = (uint64_t)P.grid_x * P.grid_y * P.plane_groups * insts;
-			if (int rc = check_blocks(blocks))
-				return rc;
-			const size_t smem = (size_t)P.planes_per_wg * WPLANE * sizeof(int16_t);
+			const bool streaming = stream_eligible(pl, L, u8);
 			Launch LA{pl, 0};
-			if (int rc = LA.begin())
-				return rc;
-			if (u8)
-				launch_forward<true>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
-			else
-				launch_forward<false>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
 			char name[48];
-			snprintf(name, sizeof name, "fwd_level_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			if (streaming)
+			{
+				if (u8)
+					P.planes_per_wg = 4, P.plane_groups = 1;
+				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
+				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
+				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
+				if (int rc = check_blocks(blocks))
+					return rc;
+				// int16 narrowing after every step can only be skipped where the worst-case growth of
+				// u8-sourced data provably stays inside int16: levels 0 and 1 ("ranges")
+				const bool narrow = planes || l >= 2;
+				if (int rc = LA.begin())
+					return rc;
+				if (u8)
+					launch_forward_stream<4, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+				else
+					launch_forward_stream<1, false>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+				snprintf(name, sizeof name, "fwd_stream_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			}
+			else
+			{
+				const uint64_t blocks = (uint64_t)P.grid_x * P.grid_y * P.plane_groups * insts;
+				if (int rc = check_blocks(blocks))
+					return rc;
+				const size_t smem = (size_t)P.planes_per_wg * WPLANE * sizeof(int16_t);
+				if (int rc = LA.begin())
+					return rc;
+				if (u8)
+					launch_forward<true>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+				else
+					launch_forward<false>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+				snprintf(name, sizeof name, "fwd_level_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			}
 			const uint64_t samples = (uint64_t)L.cw * L.ch * pl->channels * insts;
 			const uint64_t outs = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
 			if (int rc = LA.end(name, (uint32_t)l, (uint32_t)gi, samples, samples * (u8 ? 1 : 2), outs * 2))

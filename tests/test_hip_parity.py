@@ -42,11 +42,24 @@ def hip_decode_body(body, s, ch, w, h):
         return d_img.cpu().numpy().reshape(h, w, ch)
 
 
+@pytest.fixture(params=["auto", "generic", "stream"])
+def path_mode(request):
+    """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
+    kernels wherever they are legal (even at tiny sizes), 'auto' is what ships."""
+    old = os.environ.get("AKO_HIP_PATH")
+    os.environ["AKO_HIP_PATH"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("AKO_HIP_PATH", None)
+    else:
+        os.environ["AKO_HIP_PATH"] = old
+
+
 def test_device_present():
     assert api.device_count() >= 1
 
 
-def test_small_golden_blobs(po, golden_blobs):
+def test_small_golden_blobs(po, golden_blobs, path_mode):
     ids = sorted({k.rsplit("/", 1)[0] for k in golden_blobs.files})
     for cid in ids:
         c = parse_case_id(cid)
@@ -63,7 +76,7 @@ def test_small_golden_blobs(po, golden_blobs):
         assert np.array_equal(dec, golden_blobs[cid + "/dec"]), cid
 
 
-def test_grid_checksums(po, golden_sums):
+def test_grid_checksums(po, golden_sums, path_mode):
     for cid, exp in golden_sums["grid"].items():
         c = parse_case_id(cid)
         img = case_input(po, c)
@@ -80,7 +93,7 @@ def test_grid_checksums(po, golden_sums):
         assert f"{po.adler32(dec):08x}" == exp["decoded"]["adler32"], cid
 
 
-def test_random_sweep_against_oracle(po):
+def test_random_sweep_against_oracle(po, path_mode):
     """All wavelets x wraps x odd / even extents x 1..5 channels x q / g x tiles x colour x discard."""
     rng = random.Random(4321)
     nrng = np.random.default_rng(9)
@@ -115,7 +128,30 @@ def test_random_sweep_against_oracle(po):
     assert done > 150
 
 
-def test_adversarial_streams_decode_alike(po):
+def test_wide_images_all_wraps(po, path_mode):
+    """Widths spanning several 120-column strips and heights spanning several row segments, every
+    wrap mode and wavelet, even and odd extents (odd widths fall back to the window engine)."""
+    nrng = np.random.default_rng(21)
+    os.environ["AKO_HIP_SEG_ROWS"] = "16"
+    try:
+        for (w, h) in [(512, 96), (250, 130), (736, 66), (1000, 77), (244, 512), (255, 64)]:
+            for wavelet in (0, 1, 2):
+                for wrap in range(4):
+                    for (q, g) in ((0, 0), (16, 16)):
+                        img = nrng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+                        s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=g)
+                        ob, st = po.encode_image(s, img)
+                        assert st == 0
+                        body = hip_encode_body(img, s)
+                        assert np.array_equal(body, ob[16:]), (w, h, wavelet, wrap, q)
+                        od, os_, _ = po.decode_image(ob)
+                        dec = hip_decode_body(ob[16:], os_, 4, w, h)
+                        assert np.array_equal(dec, od), (w, h, wavelet, wrap, q)
+    finally:
+        os.environ.pop("AKO_HIP_SEG_ROWS", None)
+
+
+def test_adversarial_streams_decode_alike(po, path_mode):
     """Full-range int16 coefficient streams: every int16 wrap-around in the inverse path must agree."""
     rng = random.Random(77)
     nrng = np.random.default_rng(5)
@@ -137,7 +173,7 @@ def test_adversarial_streams_decode_alike(po):
         assert np.array_equal(dec, od), (w, h, ch, s.wavelet, s.wrap, s.color)
 
 
-def test_planes_lifting_only_small(po):
+def test_planes_lifting_only_small(po, path_mode):
     """PLANES_I16 mode (BASELINE configs[1] shape): int16 planes <-> streams, no colour, lossless."""
     for (w, h, wv, wrap, tiles) in [(256, 256, 0, 0, 0), (100, 75, 0, 2, 0), (130, 67, 1, 1, 0), (64, 200, 2, 3, 0),
                                     (96, 80, 0, 0, 32)]:
