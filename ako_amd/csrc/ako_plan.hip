@@ -270,14 +270,15 @@ int path_mode()
 	return PATH_AUTO;
 }
 
-// streaming kernels need an even level width (no phantom column) of at least 8 samples;
+// streaming kernels need a level width that is a multiple of 4 (no phantom column, and an even
+// number of coefficient columns so that a lane's column pair is never split by the border);
 // in AUTO mode they are used where they pay: wide levels
 bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 {
 	const int mode = path_mode();
 	if (mode == PATH_GENERIC)
 		return false;
-	if ((L.cw & 1) != 0 || L.cw < 8 || L.tw < 4 || L.th < 2)
+	if ((L.cw & 3) != 0 || L.cw < 8 || L.th < 2)
 		return false;
 	if (u8 && pl->channels != 4)
 		return false;
