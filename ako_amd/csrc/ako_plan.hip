@@ -331,6 +331,17 @@ void launch_forward_stream(int kind, bool narrow, const LevelParams& P, const St
 #undef AKO_FS
 }
 
+template <int NPL, bool U8>
+void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, hipStream_t st)
+{
+	if (kind == K_DD137)
+		hipLaunchKernelGGL((k_inverse_stream<K_DD137, NPL, U8>), dim3(blocks), dim3(THREADS), 0, st, P, G);
+	else if (kind == K_CDF53)
+		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8>), dim3(blocks), dim3(THREADS), 0, st, P, G);
+	else
+		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8>), dim3(blocks), dim3(THREADS), 0, st, P, G);
+}
+
 int check_blocks(uint64_t blocks)
 {
 	if (blocks == 0 || blocks > 0x7FFFFFFFull)
@@ -537,19 +548,40 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				P.dst_inst_stride = P.dst_plane_stride * pl->channels;
 			}
 
-			const uint64_t blocks = (uint64_t)P.grid_x * P.grid_y * P.plane_groups * insts;
-			if (int rc = check_blocks(blocks))
-				return rc;
-			const size_t smem = (size_t)P.planes_per_wg * WPLANE * sizeof(int16_t);
+			const bool streaming = stream_eligible(pl, L, u8);
 			Launch LA{pl, 1};
-			if (int rc = LA.begin())
-				return rc;
-			if (u8)
-				launch_inverse<true>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
-			else
-				launch_inverse<false>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
 			char name[48];
-			snprintf(name, sizeof name, "inv_level_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			if (streaming)
+			{
+				if (u8)
+					P.planes_per_wg = 4, P.plane_groups = 1;
+				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
+				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
+				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
+				if (int rc = check_blocks(blocks))
+					return rc;
+				if (int rc = LA.begin())
+					return rc;
+				if (u8)
+					launch_inverse_stream<4, true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+				else
+					launch_inverse_stream<1, false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+				snprintf(name, sizeof name, "inv_stream_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			}
+			else
+			{
+				const uint64_t blocks = (uint64_t)P.grid_x * P.grid_y * P.plane_groups * insts;
+				if (int rc = check_blocks(blocks))
+					return rc;
+				const size_t smem = (size_t)P.planes_per_wg * WPLANE * sizeof(int16_t);
+				if (int rc = LA.begin())
+					return rc;
+				if (u8)
+					launch_inverse<true>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+				else
+					launch_inverse<false>(L.kind, P, (uint32_t)blocks, smem, pl->stream);
+				snprintf(name, sizeof name, "inv_level_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+			}
 			const uint64_t samples = (uint64_t)L.cw * L.ch * pl->channels * insts;
 			const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
 			if (int rc = LA.end(name, (uint32_t)l, (uint32_t)gi, samples, ins * 2, samples * (u8 ? 1 : 2)))

@@ -3,33 +3,53 @@
 // Same arithmetic as the generic window engine (ako_kernels.hip.h), different data movement:
 //
 //   * NO LDS and NO barriers.  One wave64 owns a vertical strip of 128 coefficient columns
-//     (120 net + 4 halo columns on either side) and walks it top to bottom.
+//     (120 net + 4 halo columns on either side) and walks a segment of it top to bottom.
 //   * every lane owns two adjacent coefficient columns (four samples of a row): on the u8 side
-//     that is one 16-byte load of four RGBA pixels per lane and row, on int16 planes one 8-byte load
+//     that is one 16-byte load / store of four RGBA pixels per lane and row
 //   * the horizontal pass takes its neighbour taps from the adjacent lanes with DPP whole-wave
-//     shifts (wave_shr:1 / wave_shl:1) -- 6 per row for DD13/7, 2 for CDF5/3
-//   * the vertical pass is a software pipeline in registers: each lane keeps, per column, the last
-//     three even rows, two odd rows and three high-pass rows; a new row pair in, one finished
-//     low-pass row and one high-pass row out
-//   * colour transform is fused in front (forward) / behind (inverse); gate + quantization and
-//     the stream packing are fused into the stores (forward), de-quantization into the loads
+//     shifts (wave_shr:1 / wave_shl:1) -- 6 per row and plane for DD13/7, 2 for CDF5/3
+//   * the vertical pass is a software pipeline in registers: per column a lane keeps the last few
+//     rows of each sequence in small rings; the row loop is unrolled by 6 (= lcm of the ring
+//     periods) so that ring indices are compile-time constants and no register moves are needed
+//   * row data is prefetched two row-slots ahead of its use
+//   * colour transform is fused in front (forward) / behind (inverse); gate + quantization and the
+//     stream packing are fused into the stores (forward), de-quantization into the loads (inverse)
 //
 // Boundary rules are the same closed form as in the window engine:
 //   rows   : the row slot fed to the pipeline is map_index(v) (CLAMP/MIRROR nearest, REPEAT modulo,
-//            ZERO zeros); the high-pass halo slots are patched in the pipeline (nearest / zero)
+//            ZERO zeros); the halo slots of the sequence the first step produces are patched in
+//            the pipeline (nearest / zero)
 //   columns: REPEAT wraps the lane's load address; CLAMP/MIRROR/ZERO overwrite the out-of-range
-//            lanes of the even sequence and then of the high-pass sequence (v_readlane broadcast)
+//            lanes of the input sequence and then of the produced sequence (v_readlane broadcast)
 //   MIRROR : the far taps take the opposite near tap
-// Levels with an odd width, and everything small, stay on the window engine.
+// The boundary code is compiled out (template flags HEDGE / VEDGE) for waves whose strip / segment
+// does not touch a tile border.  Levels whose width is not a multiple of 4, and everything small,
+// stay on the window engine.
 #pragma once
 
 #include "ako_kernels.hip.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace ako
 {
 
+// compile-time unrolled loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>)
+template <int... Ks, typename F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Ks...>, F&& f)
+{
+	(f(std::integral_constant<int, Ks>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+	static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 constexpr int SNET = 120;  // net coefficient columns per wave
 constexpr int SORG = 4;    // lane 0 holds coefficient columns strip * SNET - SORG, +1
+constexpr int SWAVES = THREADS / 64;
 
 // lane i <- lane i-1 / lane i+1 over the whole wave64 (gfx9 DPP wave shifts)
 __device__ __forceinline__ int from_prev_lane(int x)
@@ -47,20 +67,57 @@ __device__ __forceinline__ int nrw(int v)
 	return NARROW ? (int)(int16_t)v : v;
 }
 
-// what a wave needs to know about the left / right tile border
+// lifting terms (wavelet-dd137.c:36-54, wavelet-cdf53.c:36-54); P = predict-like, U = update-like
+template <int KIND>
+__device__ __forceinline__ int term_p(int l1, int e, int p1, int p2)
+{
+	if (KIND == K_DD137)
+		return tdiv(l1 + p2 - 9 * (e + p1), 4);
+	if (KIND == K_CDF53)
+		return -tdiv(e + p1, 1);
+	return -e;
+}
+template <int KIND>
+__device__ __forceinline__ int term_u(int l2, int l1, int h, int p1)
+{
+	if (KIND == K_DD137)
+		return tdiv(-l2 - p1 + 9 * (l1 + h), 5);
+	if (KIND == K_CDF53)
+		return tdiv(l1 + h, 2);
+	return 0;
+}
+
+// what a lane needs to know about the left / right tile border
 struct HEdge
 {
-	bool left, right;  // this strip holds out-of-range lanes on that side (never set for REPEAT)
-	bool oob_l, oob_r; // this lane is such a lane
-	bool last;         // this lane holds columns T-2, T-1
-	bool first;        // this lane holds columns 0, 1
+	bool left, right;   // this strip holds out-of-range lanes on that side (never set for REPEAT)
+	bool oob_l, oob_r;  // this lane is such a lane
+	bool first, last;   // this lane holds columns 0,1 / T-2,T-1
 	int lane_first, lane_last;
 	int wrap;
 };
 
+// overwrite the out-of-range lanes of a two-column sequence (a0 = column c0, a1 = column c1) with
+// its nearest in-range value (CLAMP / MIRROR) or zero
+__device__ __forceinline__ void fix_halo_lanes(int& a0, int& a1, const HEdge& ed)
+{
+	if (ed.left)
+	{
+		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(a0, ed.lane_first);
+		if (ed.oob_l)
+			a0 = f, a1 = f;
+	}
+	if (ed.right)
+	{
+		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(a1, ed.lane_last);
+		if (ed.oob_r)
+			a0 = f, a1 = f;
+	}
+}
+
 // Horizontal forward lift of one row: samples (E0 O0 E1 O1) of this lane's two coefficient
 // columns -> (L0 L1 H0 H1).  Valid in lanes 2..61.
-template <int KIND, bool NARROW>
+template <int KIND, bool NARROW, bool HEDGE>
 __device__ __forceinline__ void hlift_forward(int E0, int O0, int E1, int O1, const HEdge& ed, int& L0, int& L1,
                                               int& H0, int& H1)
 {
@@ -70,130 +127,153 @@ __device__ __forceinline__ void hlift_forward(int E0, int O0, int E1, int O1, co
 		H0 = nrw<true>(O0 - E0), H1 = nrw<true>(O1 - E1);
 		return;
 	}
-	if (ed.left)
-	{
-		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(E0, ed.lane_first);
-		if (ed.oob_l)
-			E0 = f, E1 = f;
-	}
-	if (ed.right)
-	{
-		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(E1, ed.lane_last);
-		if (ed.oob_r)
-			E0 = f, E1 = f;
-	}
+	if (HEDGE)
+		fix_halo_lanes(E0, E1, ed);
 
-	if (KIND == K_CDF53)
-	{
-		const int eR0 = from_next_lane(E0);
-		H0 = nrw<NARROW>(O0 - tdiv(E0 + E1, 1));
-		H1 = nrw<NARROW>(O1 - tdiv(E1 + eR0, 1));
-	}
-	else
-	{
-		const int eL = from_prev_lane(E1);
-		const int eR0 = from_next_lane(E0);
-		const int eR1 = from_next_lane(E1);
-		int p2_0 = eR0, p2_1 = eR1;
-		if (ed.right && ed.wrap == W_MIRROR && ed.last)
-			p2_0 = eL, p2_1 = E0;  // far tap := opposite near tap
-		H0 = nrw<NARROW>(O0 + tdiv(eL + p2_0 - 9 * (E0 + E1), 4));
-		H1 = nrw<NARROW>(O1 + tdiv(E0 + p2_1 - 9 * (E1 + eR0), 4));
-	}
+	const int eR0 = from_next_lane(E0);
+	int eL = 0, eR1 = 0;
+	if (KIND == K_DD137)
+		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	int p2_0 = eR0, p2_1 = eR1;
+	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.last)
+		p2_0 = eL, p2_1 = E0;  // far tap := opposite near tap
+	H0 = nrw<NARROW>(O0 + term_p<KIND>(eL, E0, E1, p2_0));
+	H1 = nrw<NARROW>(O1 + term_p<KIND>(E0, E1, eR0, p2_1));
 
-	if (ed.left)
-	{
-		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(H0, ed.lane_first);
-		if (ed.oob_l)
-			H0 = f, H1 = f;
-	}
-	if (ed.right)
-	{
-		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(H1, ed.lane_last);
-		if (ed.oob_r)
-			H0 = f, H1 = f;
-	}
+	if (HEDGE)
+		fix_halo_lanes(H0, H1, ed);
 
-	if (KIND == K_CDF53)
-	{
-		const int hL1 = from_prev_lane(H1);
-		L0 = nrw<NARROW>(E0 + tdiv(hL1 + H0, 2));
-		L1 = nrw<NARROW>(E1 + tdiv(H0 + H1, 2));
-	}
-	else
-	{
-		const int hL0 = from_prev_lane(H0);
-		const int hL1 = from_prev_lane(H1);
-		const int hR0 = from_next_lane(H0);
-		int l2_0 = hL0, l2_1 = hL1;
-		if (ed.left && ed.wrap == W_MIRROR && ed.first)
-			l2_0 = H1, l2_1 = hR0;
-		L0 = nrw<NARROW>(E0 + tdiv(-l2_0 - H1 + 9 * (hL1 + H0), 5));
-		L1 = nrw<NARROW>(E1 + tdiv(-l2_1 - hR0 + 9 * (H0 + H1), 5));
-	}
+	const int hL1 = from_prev_lane(H1);
+	int hL0 = 0, hR0 = 0;
+	if (KIND == K_DD137)
+		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	int l2_0 = hL0, l2_1 = hL1;
+	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.first)
+		l2_0 = H1, l2_1 = hR0;
+	L0 = nrw<NARROW>(E0 + term_u<KIND>(l2_0, hL1, H0, H1));
+	L1 = nrw<NARROW>(E1 + term_u<KIND>(l2_1, H0, H1, hR0));
 }
 
-// vertical pipeline state of one column
-struct VCol
+// Horizontal inverse lift of one row: (L0 L1 H0 H1) -> samples (E0 O0 E1 O1).  Valid in lanes 2..61.
+template <int KIND, bool HEDGE>
+__device__ __forceinline__ void hlift_inverse(int L0, int L1, int H0, int H1, const HEdge& ed, int& E0, int& O0,
+                                              int& E1, int& O1)
 {
-	int eA, eB, eC;  // E[v-3], E[v-2], E[v-1]
-	int oA, oB;      // O[v-2], O[v-1]
-	int hA, hB, hC;  // HP[v-5], HP[v-4], HP[v-3]
-};
+	if (KIND == K_HAAR)
+	{
+		E0 = L0, E1 = L1;
+		O0 = nrw<true>(L0 + H0), O1 = nrw<true>(L1 + H1);
+		return;
+	}
+	if (HEDGE)
+		fix_halo_lanes(H0, H1, ed);
 
-// what a wave needs to know about the top / bottom tile border at slot v
-struct VEdge
+	const int hL1 = from_prev_lane(H1);
+	int hL0 = 0, hR0 = 0;
+	if (KIND == K_DD137)
+		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	int l2_0 = hL0, l2_1 = hL1;
+	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.first)
+		l2_0 = H1, l2_1 = hR0;
+	E0 = nrw<true>(L0 - term_u<KIND>(l2_0, hL1, H0, H1));
+	E1 = nrw<true>(L1 - term_u<KIND>(l2_1, H0, H1, hR0));
+
+	if (HEDGE)
+		fix_halo_lanes(E0, E1, ed);
+
+	const int eR0 = from_next_lane(E0);
+	int eL = 0, eR1 = 0;
+	if (KIND == K_DD137)
+		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	int p2_0 = eR0, p2_1 = eR1;
+	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.last)
+		p2_0 = eL, p2_1 = E0;
+	O0 = nrw<true>(H0 - term_p<KIND>(eL, E0, E1, p2_0));
+	O1 = nrw<true>(H1 - term_p<KIND>(E0, E1, eR0, p2_1));
+}
+
+// ---- vertical pipelines ---------------------------------------------------------------------
+// Rings are indexed with the unroll position K (0..5) of the row loop; all indices are constants.
+
+struct VFwd  // forward: E[v-3..v-1] in e[], O[v-2..v-1] in o[], HP[v-5..v-3] in h[]
 {
-	int wrap, T;
+	int e[3], o[2], h[3];
 };
 
 // Feed row slot v (even value E, odd value O); returns LP[v-3] and HP[v-3].
-template <int KIND, bool NARROW>
-__device__ __forceinline__ void vstep_forward(VCol& s, int E, int O, int v, const VEdge& ed, int& lp_out, int& hp_out)
+template <int KIND, bool NARROW, bool VEDGE, int K>
+__device__ __forceinline__ void vstep_forward(VFwd& s, int E, int O, int v, int wrap, int T, int& lp_out,
+                                              int& hp_out)
 {
-	const int u = v - 2;  // high-pass slot produced now
-	const int r = v - 3;  // row finished now
-	int H;
-	if (KIND == K_HAAR)
-		H = nrw<true>(s.oA - s.eB);
-	else if (KIND == K_CDF53)
-		H = nrw<NARROW>(s.oA - tdiv(s.eB + s.eC, 1));
-	else
+	// ring slots at unroll position K
+	int& eA = s.e[K % 3];        // E[v-3]   (overwritten by E[v] at the end)
+	int& eB = s.e[(K + 1) % 3];  // E[v-2]
+	int& eC = s.e[(K + 2) % 3];  // E[v-1]
+	int& oA = s.o[K % 2];        // O[v-2]   (overwritten by O[v])
+	int& hA = s.h[K % 3];        // HP[v-5]  (overwritten by HP[v-2])
+	int& hB = s.h[(K + 1) % 3];  // HP[v-4]
+	int& hC = s.h[(K + 2) % 3];  // HP[v-3]
+
+	const int u = v - 2, r = v - 3;
+	int p2 = E;
+	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && u + 2 >= T)
+		p2 = eA;
+	int H = nrw < NARROW || KIND == K_HAAR > (oA + term_p<KIND>(eA, eB, eC, p2));
+	if (VEDGE && KIND != K_HAAR && wrap != W_REPEAT)
 	{
-		int p2 = E;
-		if (ed.wrap == W_MIRROR && u + 2 >= ed.T)
-			p2 = s.eA;
-		H = nrw<NARROW>(s.oA + tdiv(s.eA + p2 - 9 * (s.eB + s.eC), 4));
-	}
-	// halo slots of the high-pass sequence
-	if (KIND != K_HAAR && ed.wrap != W_REPEAT)
-	{
-		if (u >= ed.T)
-			H = (ed.wrap == W_ZERO) ? 0 : s.hC;  // HP[T-1] again (u == T is the only such slot consumed)
-		if (u < 0 && ed.wrap == W_ZERO)
+		if (u >= T)
+			H = (wrap == W_ZERO) ? 0 : hC;  // HP[T] := HP[T-1]
+		if (u < 0 && wrap == W_ZERO)
 			H = 0;
-		if (u == 0 && ed.wrap != W_ZERO)
-			s.hB = H, s.hC = H;  // HP[-2] = HP[-1] = HP[0]
+		if (u == 0 && wrap != W_ZERO)
+			hB = H, hC = H;  // HP[-2] = HP[-1] := HP[0]
 	}
+	int l2 = hA;
+	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && r < 2)
+		l2 = H;
+	lp_out = nrw<NARROW>(eA + term_u<KIND>(l2, hB, hC, H));
+	hp_out = hC;
+	eA = E, oA = O, hA = H;
+}
 
-	int L;
-	if (KIND == K_HAAR)
-		L = s.eA;
-	else if (KIND == K_CDF53)
-		L = nrw<NARROW>(s.eA + tdiv(s.hB + s.hC, 2));
-	else
+struct VInv  // inverse: HP[v-3..v-1] in h[], LP[v-1] in l, E[v-4..v-2] in e[]
+{
+	int h[3], e[3], l;
+};
+
+// Feed quadrant row slot v (low-pass value LP, high-pass value HP); returns the even and the odd
+// sample row of slot v-3.
+template <int KIND, bool VEDGE, int K>
+__device__ __forceinline__ void vstep_inverse(VInv& s, int LP, int HP, int v, int wrap, int T, int& even_out,
+                                              int& odd_out)
+{
+	int& hA = s.h[K % 3];        // HP[v-3]  (overwritten by HP[v])
+	int& hB = s.h[(K + 1) % 3];  // HP[v-2]
+	int& hC = s.h[(K + 2) % 3];  // HP[v-1]
+	int& eA = s.e[K % 3];        // E[v-4]   (overwritten by E[v-1])
+	int& eB = s.e[(K + 1) % 3];  // E[v-3]
+	int& eC = s.e[(K + 2) % 3];  // E[v-2]
+
+	const int re = v - 1, ro = v - 3;
+	int l2 = hA;
+	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && re < 2)
+		l2 = HP;
+	int Ev = nrw<true>(s.l - term_u<KIND>(l2, hB, hC, HP));
+	if (VEDGE && KIND != K_HAAR && wrap != W_REPEAT)
 	{
-		int l2 = s.hA;
-		if (ed.wrap == W_MIRROR && r < 2)
-			l2 = H;
-		L = nrw<NARROW>(s.eA + tdiv(-l2 - H + 9 * (s.hB + s.hC), 5));
+		if (re >= T)
+			Ev = (wrap == W_ZERO) ? 0 : eC;  // E[T] := E[T-1]
+		if (re < 0 && wrap == W_ZERO)
+			Ev = 0;
+		if (ro == 0)
+			eA = (wrap == W_ZERO) ? 0 : eB;  // E[-1] := E[0]
 	}
-	lp_out = L;
-	hp_out = s.hC;
-
-	s.eA = s.eB, s.eB = s.eC, s.eC = E;
-	s.oA = s.oB, s.oB = O;
-	s.hA = s.hB, s.hB = s.hC, s.hC = H;
+	int p2 = Ev;
+	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && ro + 2 >= T)
+		p2 = eA;
+	even_out = eB;
+	odd_out = nrw<true>(hA - term_p<KIND>(eA, eB, eC, p2));
+	hA = HP, s.l = LP, eA = Ev;
 }
 
 struct StreamGeom
@@ -211,7 +291,7 @@ struct UnitId
 __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const StreamGeom& G)
 {
 	UnitId id;
-	uint64_t u = (uint64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+	uint64_t u = (uint64_t)blockIdx.x * SWAVES + (threadIdx.x >> 6);
 	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
 	id.valid = u < total;
 	id.strip = (uint32_t)(u % G.strips);
@@ -229,10 +309,264 @@ __device__ __forceinline__ uint32_t pack2(int lo, int hi)
 {
 	return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
 }
+__device__ __forceinline__ int lo16(uint32_t w)
+{
+	return (int)(int16_t)(w & 0xFFFFu);
+}
+__device__ __forceinline__ int hi16(uint32_t w)
+{
+	return (int)w >> 16;
+}
+
+// per lane column geometry shared by both directions
+struct LaneCols
+{
+	int c0;   // first of the lane's two coefficient columns
+	int xs;   // first of the lane's four samples (clamped / wrapped so that the access is in range)
+	int cs;   // first of the lane's two coefficient columns, clamped / wrapped likewise
+	HEdge he;
+	bool hedge;
+};
+
+__device__ __forceinline__ LaneCols lane_columns(uint32_t strip, int lane, int Tc, int wrap)
+{
+	LaneCols lc;
+	const int c_base = (int)strip * SNET - SORG;
+	lc.c0 = c_base + 2 * lane;
+	lc.he.wrap = wrap;
+	lc.he.left = (wrap != W_REPEAT) && (c_base < 0);
+	lc.he.right = (wrap != W_REPEAT) && (c_base + 128 > Tc);
+	lc.he.oob_l = lc.c0 < 0;
+	lc.he.oob_r = lc.c0 >= Tc;
+	lc.he.lane_first = SORG / 2;
+	lc.he.lane_last = (Tc - 2 - c_base) / 2;
+	lc.he.first = (lc.c0 == 0);
+	lc.he.last = (lc.c0 == Tc - 2);
+	lc.hedge = lc.he.left || lc.he.right;
+	if (wrap == W_REPEAT)
+	{
+		int cm = lc.c0 % Tc;
+		if (cm < 0)
+			cm += Tc;
+		lc.cs = cm;
+	}
+	else
+		lc.cs = min(max(lc.c0, 0), Tc - 2);
+	lc.xs = 2 * lc.cs;
+	return lc;
+}
+
+// forward colour transform of one pixel (format.c:87-134)
+__device__ __forceinline__ void color_forward(int color, int r, int g, int b, int& c0, int& c1, int& c2)
+{
+	c0 = r, c1 = g, c2 = b;
+	if (color == C_SUBG)
+		c0 = g, c1 = r - g, c2 = b - g;
+	else if (color != C_NONE)
+	{
+		const int co = r - b;
+		const int t = b + tdiv(co, 1);
+		const int cg = g - t;
+		const int yy = t + tdiv(cg, 1);
+		c0 = (color == C_YCOCG_Q) ? yy * 2 : yy;
+		c1 = co, c2 = cg;
+	}
+}
+
+// inverse colour transform of one pixel (format.c:138-218), int16 wrap after every step
+__device__ __forceinline__ void color_inverse(int color, int v0, int v1, int v2, int& r, int& g, int& b)
+{
+	r = v0, g = v1, b = v2;
+	if (color == C_SUBG)
+		r = (int16_t)(v1 + v0), g = v0, b = (int16_t)(v2 + v0);
+	else if (color != C_NONE)
+	{
+		const int yv = (color == C_YCOCG_Q) ? tdiv(v0, 1) : v0;
+		const int t = (int16_t)(yv - tdiv(v2, 1));
+		g = (int16_t)(v2 + t);
+		b = (int16_t)(t - tdiv(v1, 1));
+		r = (int16_t)(b + v1);
+	}
+}
 
 // ---------------------------------------------------------------------------------------------
 // Forward.  NPL = planes handled by one wave: 4 with U8 (RGBA pixels), 1 on int16 planes.
 // ---------------------------------------------------------------------------------------------
+
+template <bool U8>
+struct FwdRaw
+{
+	using vec = uint4;  // U8: four RGBA pixels
+	vec a[2];           // the two rows of a slot
+};
+template <>
+struct FwdRaw<false>
+{
+	using vec = uint2;  // int16: four samples
+	vec a[2];
+};
+
+template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE>
+__device__ __forceinline__ void forward_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
+                                                    const LaneCols& lc, int lane)
+{
+	const TileDesc td = P.tiles[id.tile];
+	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
+	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
+	const int chh = (int)P.full_h;
+	const int wrap = P.wrap;
+	const int p_first = U8 ? 0 : (int)id.pg;
+	const int c0 = lc.c0;
+
+	const int r_lo = (int)id.seg * (int)G.seg_rows;
+	const int r_hi = min(r_lo + (int)G.seg_rows, Tr);
+
+	// sources
+	const uint8_t* img = nullptr;
+	const int16_t* src = nullptr;
+	uint64_t row_pitch;  // bytes (U8) or elements (int16)
+	if (U8)
+	{
+		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0 + lc.xs) * 4;
+		row_pitch = (uint64_t)P.img_pitch * 4;
+	}
+	else
+	{
+		src = P.src + (P.src_tiled ? (uint64_t)id.image : inst) * P.src_inst_stride +
+		      (uint64_t)p_first * P.src_plane_stride + lc.xs;
+		if (P.src_tiled)
+			src += (uint64_t)td.y0 * P.src_pitch + td.x0;
+		row_pitch = P.src_pitch;
+	}
+
+	// destinations
+	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+	const uint64_t nsub = (uint64_t)Tc * Tr;
+	const bool store_lane = (lane >= 2) && (lane < 62) && (c0 >= 0) && (c0 < Tc);
+	int16_t* ll_base[NPL];
+	int16_t* grp_base[NPL];
+	uint32_t ll_pitch = (uint32_t)Tc;
+#pragma unroll
+	for (int p = 0; p < NPL; p++)
+	{
+		const int pl = p_first + p;
+		grp_base[p] = tile_stream + P.grp_off[pl] + 1 + c0;
+		if (P.ll_out_stream)
+			ll_base[p] = tile_stream + P.lp_off[pl] + c0;
+		else
+		{
+			ll_base[p] = P.dst + inst * P.dst_inst_stride + (uint64_t)pl * P.dst_plane_stride + c0;
+			ll_pitch = P.dst_pitch;
+		}
+	}
+
+	if (id.strip == 0 && id.seg == 0 && lane == 0)
+#pragma unroll
+		for (int p = 0; p < NPL; p++)
+			tile_stream[P.grp_off[p_first + p]] = (int16_t)((p_first + p == 0) ? P.q_luma : P.q_chroma);
+
+	VFwd st[NPL][4];
+#pragma unroll
+	for (int p = 0; p < NPL; p++)
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			st[p][k] = VFwd{{0, 0, 0}, {0, 0}, {0, 0, 0}};
+
+	using Raw = FwdRaw<U8>;
+	using RawVec = typename Raw::vec;
+	auto fetch = [&](int v, Raw& raw) {
+		const int m = VEDGE ? map_index(v, Tr, wrap) : v;
+#pragma unroll
+		for (int par = 0; par < 2; par++)
+		{
+			const int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
+			if (U8)
+				raw.a[par] = *reinterpret_cast<const RawVec*>(img + (uint64_t)y * row_pitch);
+			else
+				raw.a[par] = *reinterpret_cast<const RawVec*>(src + (uint64_t)y * row_pitch);
+		}
+	};
+
+	const int v_begin = r_lo - 3;
+	const int n_slots = r_hi + 3 - v_begin;
+	Raw ring[3];
+	fetch(v_begin, ring[0]);
+	fetch(v_begin + 1, ring[1]);
+
+	for (int base = 0; base < n_slots; base += 6)
+	{
+		static_for<6>([&](auto kc) {
+			constexpr int K = decltype(kc)::value;
+			const int v = v_begin + base + K;
+			fetch(v + 2, ring[(K + 2) % 3]);  // prefetch two slots ahead (clamped rows: always in range)
+			const Raw& raw = ring[K % 3];
+			const bool zero_row = VEDGE && (wrap == W_ZERO) && ((unsigned)v >= (unsigned)Tr);
+
+			int smp[2][NPL][4];
+#pragma unroll
+			for (int par = 0; par < 2; par++)
+			{
+				if constexpr (U8)
+				{
+					const uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+					{
+						int r = px[k] & 255, g = (px[k] >> 8) & 255, b = (px[k] >> 16) & 255, a = px[k] >> 24;
+						if (P.discard && a == 0)
+							r = g = b = 0;
+						int c0v, c1v, c2v;
+						color_forward(P.color, r, g, b, c0v, c1v, c2v);
+						smp[par][0][k] = zero_row ? 0 : c0v;
+						smp[par][1 % NPL][k] = zero_row ? 0 : c1v;
+						smp[par][2 % NPL][k] = zero_row ? 0 : c2v;
+						smp[par][3 % NPL][k] = zero_row ? 0 : a;
+					}
+				}
+				else
+				{
+					smp[par][0][0] = zero_row ? 0 : lo16(raw.a[par].x);
+					smp[par][0][1] = zero_row ? 0 : hi16(raw.a[par].x);
+					smp[par][0][2] = zero_row ? 0 : lo16(raw.a[par].y);
+					smp[par][0][3] = zero_row ? 0 : hi16(raw.a[par].y);
+				}
+			}
+
+			const int r = v - 3;
+			const bool store_row = (r >= r_lo) && (r < r_hi) && store_lane;
+#pragma unroll
+			for (int p = 0; p < NPL; p++)
+			{
+				int e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
+				hlift_forward<KIND, NARROW, HEDGE>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], lc.he,
+				                                   e[0], e[1], e[2], e[3]);
+				hlift_forward<KIND, NARROW, HEDGE>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], lc.he,
+				                                   o[0], o[1], o[2], o[3]);
+				int lp[4], hp[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					vstep_forward<KIND, NARROW, VEDGE, K>(st[p][k], e[k], o[k], v, wrap, Tr, lp[k], hp[k]);
+
+				if (store_row)
+				{
+					const int pl = p_first + p;
+					const int q = (pl == 0) ? P.q_luma : P.q_chroma;
+					const int g = (pl == 0) ? P.g_luma : P.g_chroma;
+					const float rq = (pl == 0) ? P.rq_luma : P.rq_chroma;
+					int16_t* grp = grp_base[p] + (uint64_t)r * Tc;
+					// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
+					*reinterpret_cast<uint32_t*>(ll_base[p] + (uint64_t)r * ll_pitch) = pack2(lp[0], lp[1]);
+					*reinterpret_cast<uint32_t*>(grp) =
+					    pack2(quantize(hp[0], q, g, rq), quantize(hp[1], q, g, rq));
+					*reinterpret_cast<uint32_t*>(grp + nsub) =
+					    pack2(quantize(lp[2], q, g, rq), quantize(lp[3], q, g, rq));
+					*reinterpret_cast<uint32_t*>(grp + 2 * nsub) =
+					    pack2(quantize(hp[2], q, g, rq), quantize(hp[3], q, g, rq));
+				}
+			}
+		});
+	}
+}
 
 template <int KIND, int NPL, bool U8, bool NARROW>
 __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P, const StreamGeom G)
@@ -241,172 +575,224 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, lane, (int)P.sub_w, P.wrap);
+	// segment touches the top / bottom border (or wraps over it): needs the row boundary code
+	const int r_lo = (int)id.seg * (int)G.seg_rows;
+	// (the unrolled row loop may run up to 5 slots past the segment and prefetches 2 further)
+	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
+	if (lc.hedge)
+	{
+		if (vedge)
+			forward_stream_body<KIND, NPL, U8, NARROW, true, true>(P, G, id, lc, lane);
+		else
+			forward_stream_body<KIND, NPL, U8, NARROW, true, false>(P, G, id, lc, lane);
+	}
+	else
+	{
+		if (vedge)
+			forward_stream_body<KIND, NPL, U8, NARROW, false, true>(P, G, id, lc, lane);
+		else
+			forward_stream_body<KIND, NPL, U8, NARROW, false, false>(P, G, id, lc, lane);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inverse.  NPL = planes handled by one wave: 4 with U8 (RGBA pixels out), 1 on int16 planes.
+// ---------------------------------------------------------------------------------------------
+
+template <int NPL>
+struct InvRaw
+{
+	uint32_t ll[NPL], c[NPL], b[NPL], d[NPL];  // two coefficients each
+};
+
+template <int KIND, int NPL, bool U8, bool HEDGE, bool VEDGE>
+__device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
+                                                    const LaneCols& lc, int lane)
+{
 	const TileDesc td = P.tiles[id.tile];
 	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
-
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
-	const int cw = (int)P.full_w, chh = (int)P.full_h;
+	const int ow = (int)P.full_w, oh = (int)P.full_h;
 	const int wrap = P.wrap;
 	const int p_first = U8 ? 0 : (int)id.pg;
+	const int c0 = lc.c0;
 
-	// columns of this lane
-	const int c_base = (int)id.strip * SNET - SORG;
-	const int c0 = c_base + 2 * lane;
-	HEdge he;
-	he.wrap = wrap;
-	he.left = (wrap != W_REPEAT) && (c_base < 0);
-	he.right = (wrap != W_REPEAT) && (c_base + 128 > Tc);
-	he.oob_l = c0 < 0;
-	he.oob_r = c0 >= Tc;
-	he.lane_first = SORG / 2;
-	he.lane_last = (Tc - 2 - c_base) / 2;
-	he.first = (c0 == 0);
-	he.last = (c0 == Tc - 2);
-
-	int xs;  // first of this lane's four samples
-	if (wrap == W_REPEAT)
-	{
-		int cm = c0 % Tc;
-		if (cm < 0)
-			cm += Tc;
-		xs = 2 * cm;
-	}
-	else
-		xs = min(max(2 * c0, 0), cw - 4);
-
-	// rows of this wave
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	const int r_hi = min(r_lo + (int)G.seg_rows, Tr);
-	VEdge ve;
-	ve.wrap = wrap, ve.T = Tr;
 
-	// sources
-	const uint8_t* img = nullptr;
-	const int16_t* src = nullptr;
-	if (U8)
-		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0 + xs) * 4;
-	else
+	const int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+	const uint64_t nsub = (uint64_t)Tc * Tr;
+	const int16_t* ll_base[NPL];
+	const int16_t* grp_base[NPL];
+	int qv[NPL];
+	uint32_t ll_pitch = (uint32_t)Tc;
+#pragma unroll
+	for (int p = 0; p < NPL; p++)
 	{
-		src = P.src + (P.src_tiled ? (uint64_t)id.image : inst) * P.src_inst_stride +
-		      (uint64_t)p_first * P.src_plane_stride + xs;
-		if (P.src_tiled)
-			src += (uint64_t)td.y0 * P.src_pitch + td.x0;
+		const int pl = p_first + p;
+		const int16_t* grp = tile_stream + P.grp_off[pl];
+		qv[p] = grp[0];  // the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116)
+		grp_base[p] = grp + 1 + lc.cs;
+		if (P.ll_in_stream)
+			ll_base[p] = tile_stream + P.lp_off[pl] + lc.cs;
+		else
+		{
+			ll_base[p] = P.src + inst * P.src_inst_stride + (uint64_t)pl * P.src_plane_stride + lc.cs;
+			ll_pitch = P.src_pitch;
+		}
 	}
 
-	// destinations
-	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
-	const uint64_t nsub = (uint64_t)Tc * Tr;
-	const bool store_lane = (lane >= 2) && (lane < 62) && (c0 < Tc);
+	// destination
+	uint8_t* img = nullptr;
+	int16_t* dst = nullptr;
+	uint64_t out_pitch;
+	if (U8)
+	{
+		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0 + 2 * c0) * 4;
+		out_pitch = (uint64_t)P.img_pitch * 4;
+	}
+	else
+	{
+		dst = P.dst + (P.dst_tiled ? (uint64_t)id.image : inst) * P.dst_inst_stride +
+		      (uint64_t)p_first * P.dst_plane_stride + 2 * c0;
+		if (P.dst_tiled)
+			dst += (uint64_t)td.y0 * P.dst_pitch + td.x0;
+		out_pitch = P.dst_pitch;
+	}
+	// the output width is 2 * Tc here (level widths that are multiples of 4), rows may be odd in number
+	const bool store_lane = (lane >= 2) && (lane < 62) && (c0 >= 0) && (c0 < Tc);
+	(void)ow;
 
-	VCol st[NPL][4];
+	VInv st[NPL][4];
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 #pragma unroll
 		for (int k = 0; k < 4; k++)
-			st[p][k] = VCol{0, 0, 0, 0, 0, 0, 0, 0};
+			st[p][k] = VInv{{0, 0, 0}, {0, 0, 0}, 0};
 
-	if (id.strip == 0 && id.seg == 0 && lane == 0)
+	using Raw = InvRaw<NPL>;
+	auto fetch = [&](int v, Raw& raw) {
+		const int m = max(VEDGE ? map_index(v, Tr, wrap) : v, 0);
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
-			tile_stream[P.grp_off[p_first + p]] = (int16_t)((p_first + p == 0) ? P.q_luma : P.q_chroma);
-
-	for (int v = r_lo - 3; v < r_hi + 3; v++)
-	{
-		// ---- fetch the row pair of slot v ------------------------------------------------------
-		int smp[2][NPL][4];
-		const int m = map_index(v, Tr, wrap);
-#pragma unroll
-		for (int par = 0; par < 2; par++)
 		{
-			if (m < 0)
-			{
+			const int16_t* g = grp_base[p] + (uint64_t)m * Tc;
+			raw.ll[p] = *reinterpret_cast<const uint32_t*>(ll_base[p] + (uint64_t)m * ll_pitch);
+			raw.c[p] = *reinterpret_cast<const uint32_t*>(g);
+			raw.b[p] = *reinterpret_cast<const uint32_t*>(g + nsub);
+			raw.d[p] = *reinterpret_cast<const uint32_t*>(g + 2 * nsub);
+		}
+	};
+
+	const int v_begin = r_lo - 3;
+	const int n_slots = r_hi + 3 - v_begin;
+	Raw ring[3];
+	fetch(v_begin, ring[0]);
+	fetch(v_begin + 1, ring[1]);
+
+	for (int base = 0; base < n_slots; base += 6)
+	{
+		static_for<6>([&](auto kc) {
+			constexpr int K = decltype(kc)::value;
+			const int v = v_begin + base + K;
+			fetch(v + 2, ring[(K + 2) % 3]);
+			const Raw& raw = ring[K % 3];
+			const bool zero_row = VEDGE && (wrap == W_ZERO) && ((unsigned)v >= (unsigned)Tr);
+
+			const int r = v - 3;
+			const bool store_row = (r >= r_lo) && (r < r_hi) && store_lane;
+			int out[2][NPL][4];  // [row parity][plane][E0 O0 E1 O1]
 #pragma unroll
-				for (int p = 0; p < NPL; p++)
+			for (int p = 0; p < NPL; p++)
+			{
+				// columns: 0,1 = row low-pass columns c0, c1 (LL over C); 2,3 = row high-pass (B over D)
+				int lpv[4], hpv[4];
+				lpv[0] = lo16(raw.ll[p]), lpv[1] = hi16(raw.ll[p]);
+				lpv[2] = lo16(raw.b[p]), lpv[3] = hi16(raw.b[p]);
+				hpv[0] = lo16(raw.c[p]), hpv[1] = hi16(raw.c[p]);
+				hpv[2] = lo16(raw.d[p]), hpv[3] = hi16(raw.d[p]);
+				const int q = qv[p];
+				if (q > 1)  // lifting.c:30-40, int16 wrap
+				{
+					lpv[2] = (int16_t)(lpv[2] * q), lpv[3] = (int16_t)(lpv[3] * q);
 #pragma unroll
 					for (int k = 0; k < 4; k++)
-						smp[par][p][k] = 0;
-				continue;
-			}
-			const int y = min(2 * m + par, chh - 1);  // phantom last row = copy of the last row
-			if (U8)
-			{
-				const uint4 raw = *reinterpret_cast<const uint4*>(img + (uint64_t)y * P.img_pitch * 4);
-				const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
+						hpv[k] = (int16_t)(hpv[k] * q);
+				}
+				if (zero_row)
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						lpv[k] = 0, hpv[k] = 0;
+
+				int ev[4], od[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++)
-				{
-					int r = px[k] & 255, g = (px[k] >> 8) & 255, b = (px[k] >> 16) & 255, a = px[k] >> 24;
-					if (P.discard && a == 0)
-						r = g = b = 0;
-					int c0v = r, c1v = g, c2v = b;
-					if (P.color == C_SUBG)
-						c0v = g, c1v = r - g, c2v = b - g;
-					else if (P.color != C_NONE)
-					{
-						const int co = r - b;
-						const int t = b + tdiv(co, 1);
-						const int cg = g - t;
-						const int yy = t + tdiv(cg, 1);
-						c0v = (P.color == C_YCOCG_Q) ? yy * 2 : yy;
-						c1v = co, c2v = cg;
-					}
-					smp[par][0][k] = c0v;
-					if (NPL > 1)
-					{
-						smp[par][1 % NPL][k] = c1v;
-						smp[par][2 % NPL][k] = c2v;
-						smp[par][3 % NPL][k] = a;
-					}
-				}
-			}
-			else
-			{
-				const uint2 raw = *reinterpret_cast<const uint2*>(src + (uint64_t)y * P.src_pitch);
-				smp[par][0][0] = (int)(int16_t)(raw.x & 0xFFFF);
-				smp[par][0][1] = (int)raw.x >> 16;
-				smp[par][0][2] = (int)(int16_t)(raw.y & 0xFFFF);
-				smp[par][0][3] = (int)raw.y >> 16;
-			}
-		}
+					vstep_inverse<KIND, VEDGE, K>(st[p][k], lpv[k], hpv[k], v, wrap, Tr, ev[k], od[k]);
 
-		// ---- rows: horizontal lift of both rows, then columns: one pipeline step ---------------
-		const int r = v - 3;
-		const bool store_row = (r >= r_lo) && (r < r_hi) && store_lane;
-#pragma unroll
-		for (int p = 0; p < NPL; p++)
-		{
-			int e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
-			hlift_forward<KIND, NARROW>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], he, e[0], e[1], e[2],
-			                            e[3]);
-			hlift_forward<KIND, NARROW>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], he, o[0], o[1], o[2],
-			                            o[3]);
-			int lp[4], hp[4];
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				vstep_forward<KIND, NARROW>(st[p][k], e[k], o[k], v, ve, lp[k], hp[k]);
+				hlift_inverse<KIND, HEDGE>(ev[0], ev[1], ev[2], ev[3], lc.he, out[0][p][0], out[0][p][1], out[0][p][2],
+				                           out[0][p][3]);
+				hlift_inverse<KIND, HEDGE>(od[0], od[1], od[2], od[3], lc.he, out[1][p][0], out[1][p][1], out[1][p][2],
+				                           out[1][p][3]);
+			}
 
 			if (store_row)
 			{
-				const int pl = p_first + p;
-				const int q = (pl == 0) ? P.q_luma : P.q_chroma;
-				const int g = (pl == 0) ? P.g_luma : P.g_chroma;
-				const float rq = (pl == 0) ? P.rq_luma : P.rq_chroma;
-				int16_t* grp = tile_stream + P.grp_off[pl] + 1 + (uint64_t)r * Tc + c0;
-				int16_t* ll;
-				if (P.ll_out_stream)
-					ll = tile_stream + P.lp_off[pl] + (uint64_t)r * Tc + c0;
-				else
-					ll = P.dst + inst * P.dst_inst_stride + (uint64_t)pl * P.dst_plane_stride +
-					     (uint64_t)r * P.dst_pitch + c0;
-				// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
-				*reinterpret_cast<uint32_t*>(ll) = pack2(lp[0], lp[1]);
-				*reinterpret_cast<uint32_t*>(grp) = pack2(quantize(hp[0], q, g, rq), quantize(hp[1], q, g, rq));
-				*reinterpret_cast<uint32_t*>(grp + nsub) =
-				    pack2(quantize(lp[2], q, g, rq), quantize(lp[3], q, g, rq));
-				*reinterpret_cast<uint32_t*>(grp + 2 * nsub) =
-				    pack2(quantize(hp[2], q, g, rq), quantize(hp[3], q, g, rq));
+#pragma unroll
+				for (int par = 0; par < 2; par++)
+				{
+					const int y = 2 * r + par;
+					if (y >= oh)
+						continue;  // phantom last row dropped (lifting.c:112,141)
+					if constexpr (U8)
+					{
+						uint32_t px[4];
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+						{
+							int rr, gg, bb;
+							color_inverse(P.color, out[par][0][k], out[par][1 % NPL][k], out[par][2 % NPL][k], rr, gg,
+							              bb);
+							px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
+							        ((uint32_t)sat8(out[par][3 % NPL][k]) << 24);
+						}
+						*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) =
+						    make_uint4(px[0], px[1], px[2], px[3]);
+					}
+					else
+					{
+						*reinterpret_cast<uint2*>(dst + (uint64_t)y * out_pitch) =
+						    make_uint2(pack2(out[par][0][0], out[par][0][1]), pack2(out[par][0][2], out[par][0][3]));
+					}
+				}
 			}
-		}
+		});
+	}
+}
+
+template <int KIND, int NPL, bool U8>
+__global__ __launch_bounds__(THREADS) void k_inverse_stream(const LevelParams P, const StreamGeom G)
+{
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, lane, (int)P.sub_w, P.wrap);
+	const int r_lo = (int)id.seg * (int)G.seg_rows;
+	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
+	if (lc.hedge)
+	{
+		if (vedge)
+			inverse_stream_body<KIND, NPL, U8, true, true>(P, G, id, lc, lane);
+		else
+			inverse_stream_body<KIND, NPL, U8, true, false>(P, G, id, lc, lane);
+	}
+	else
+	{
+		if (vedge)
+			inverse_stream_body<KIND, NPL, U8, false, true>(P, G, id, lc, lane);
+		else
+			inverse_stream_body<KIND, NPL, U8, false, false>(P, G, id, lc, lane);
 	}
 }
 
