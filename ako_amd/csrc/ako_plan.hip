@@ -334,12 +334,13 @@ void launch_forward_stream(int kind, bool narrow, const LevelParams& P, const St
 template <int NPL, bool U8>
 void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, hipStream_t st)
 {
+	const dim3 threads(U8 ? 128 : THREADS);  // U8: the workgroup is one pair of waves (LDS plane swap)
 	if (kind == K_DD137)
-		hipLaunchKernelGGL((k_inverse_stream<K_DD137, NPL, U8>), dim3(blocks), dim3(THREADS), 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_DD137, NPL, U8>), dim3(blocks), threads, 0, st, P, G);
 	else if (kind == K_CDF53)
-		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8>), dim3(blocks), dim3(THREADS), 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8>), dim3(blocks), threads, 0, st, P, G);
 	else
-		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8>), dim3(blocks), dim3(THREADS), 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8>), dim3(blocks), threads, 0, st, P, G);
 }
 
 int check_blocks(uint64_t blocks)
@@ -452,7 +453,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			if (streaming)
 			{
 				if (u8)
-					P.planes_per_wg = 4, P.plane_groups = 1;
+					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
 				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
@@ -464,7 +465,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_forward_stream<4, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+					launch_forward_stream<2, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else
 					launch_forward_stream<1, false>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				snprintf(name, sizeof name, "fwd_stream_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
@@ -554,16 +555,17 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 			if (streaming)
 			{
 				if (u8)
-					P.planes_per_wg = 4, P.plane_groups = 1;
+					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
 				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
-				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
+				const uint32_t waves_per_block = u8 ? 2 : (THREADS / 64);
+				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
 					return rc;
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_inverse_stream<4, true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_stream<2, true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else
 					launch_inverse_stream<1, false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				snprintf(name, sizeof name, "inv_stream_%s%s", kind_name(L.kind), u8 ? "_u8" : "");

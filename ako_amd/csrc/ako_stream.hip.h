@@ -5,7 +5,11 @@
 //   * NO LDS and NO barriers.  One wave64 owns a vertical strip of 128 coefficient columns
 //     (120 net + 4 halo columns on either side) and walks a segment of it top to bottom.
 //   * every lane owns two adjacent coefficient columns (four samples of a row): on the u8 side
-//     that is one 16-byte load / store of four RGBA pixels per lane and row
+//     that is one 16-byte load / store of four RGBA pixels per lane and row.  To keep the register
+//     file at >= 2 waves per SIMD the four planes of an RGBA strip are split over a PAIR of waves
+//     (planes 0,1 and planes 2,3): forward, both waves load the same pixels (L1/L2 hits) and each
+//     colour-transforms what it needs; inverse, the pair swaps two planes of one row through LDS
+//     (16 bytes per lane and row slot, one barrier) so that each wave finishes one pixel row
 //   * the horizontal pass takes its neighbour taps from the adjacent lanes with DPP whole-wave
 //     shifts (wave_shr:1 / wave_shl:1) -- 6 per row and plane for DD13/7, 2 for CDF5/3
 //   * the vertical pass is a software pipeline in registers: per column a lane keeps the last few
@@ -291,15 +295,15 @@ struct UnitId
 __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const StreamGeom& G)
 {
 	UnitId id;
-	uint64_t u = (uint64_t)blockIdx.x * SWAVES + (threadIdx.x >> 6);
+	uint64_t u = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
 	id.valid = u < total;
+	id.pg = (uint32_t)(u % P.plane_groups);
+	u /= P.plane_groups;
 	id.strip = (uint32_t)(u % G.strips);
 	u /= G.strips;
 	id.seg = (uint32_t)(u % G.segs);
 	u /= G.segs;
-	id.pg = (uint32_t)(u % P.plane_groups);
-	u /= P.plane_groups;
 	id.tile = (uint32_t)(u % P.n_tiles);
 	id.image = (uint32_t)(u / P.n_tiles);
 	return id;
@@ -373,6 +377,16 @@ __device__ __forceinline__ void color_forward(int color, int r, int g, int b, in
 	}
 }
 
+// the two planes a wave of a pair needs from one pixel: pair 0 -> planes 0,1; pair 1 -> planes 2,3
+__device__ __forceinline__ void color_forward_pair(int color, int pair, int r, int g, int b, int a, int& v0,
+                                                   int& v1)
+{
+	int c0, c1, c2;
+	color_forward(color, r, g, b, c0, c1, c2);
+	v0 = pair ? c2 : c0;
+	v1 = pair ? a : c1;
+}
+
 // inverse colour transform of one pixel (format.c:138-218), int16 wrap after every step
 __device__ __forceinline__ void color_inverse(int color, int v0, int v1, int v2, int& r, int& g, int& b)
 {
@@ -390,7 +404,7 @@ __device__ __forceinline__ void color_inverse(int color, int v0, int v1, int v2,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward.  NPL = planes handled by one wave: 4 with U8 (RGBA pixels), 1 on int16 planes.
+// Forward.  NPL = planes handled by one wave: 2 with U8 (half of an RGBA pixel), 1 on int16 planes.
 // ---------------------------------------------------------------------------------------------
 
 template <bool U8>
@@ -415,7 +429,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
 	const int chh = (int)P.full_h;
 	const int wrap = P.wrap;
-	const int p_first = U8 ? 0 : (int)id.pg;
+	const int p_first = U8 ? 2 * (int)id.pg : (int)id.pg;
 	const int c0 = lc.c0;
 
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
@@ -515,12 +529,10 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 						int r = px[k] & 255, g = (px[k] >> 8) & 255, b = (px[k] >> 16) & 255, a = px[k] >> 24;
 						if (P.discard && a == 0)
 							r = g = b = 0;
-						int c0v, c1v, c2v;
-						color_forward(P.color, r, g, b, c0v, c1v, c2v);
-						smp[par][0][k] = zero_row ? 0 : c0v;
-						smp[par][1 % NPL][k] = zero_row ? 0 : c1v;
-						smp[par][2 % NPL][k] = zero_row ? 0 : c2v;
-						smp[par][3 % NPL][k] = zero_row ? 0 : a;
+						int v0, v1;
+						color_forward_pair(P.color, (int)id.pg, r, g, b, a, v0, v1);
+						smp[par][0][k] = zero_row ? 0 : v0;
+						smp[par][1 % NPL][k] = zero_row ? 0 : v1;
 					}
 				}
 				else
@@ -597,7 +609,8 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Inverse.  NPL = planes handled by one wave: 4 with U8 (RGBA pixels out), 1 on int16 planes.
+// Inverse.  NPL = planes handled by one wave: 2 with U8 (the workgroup is then exactly one PAIR of
+// waves working on the same strip and segment, see the file header), 1 on int16 planes.
 // ---------------------------------------------------------------------------------------------
 
 template <int NPL>
@@ -608,14 +621,15 @@ struct InvRaw
 
 template <int KIND, int NPL, bool U8, bool HEDGE, bool VEDGE>
 __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
-                                                    const LaneCols& lc, int lane)
+                                                    const LaneCols& lc, int lane, uint4 (*xbuf)[2][64])
 {
 	const TileDesc td = P.tiles[id.tile];
 	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
 	const int ow = (int)P.full_w, oh = (int)P.full_h;
 	const int wrap = P.wrap;
-	const int p_first = U8 ? 0 : (int)id.pg;
+	const int pair = (int)id.pg;  // U8: which half of the pixel this wave reconstructs
+	const int p_first = U8 ? 2 * pair : (int)id.pg;
 	const int c0 = lc.c0;
 
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
@@ -736,34 +750,50 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				                           out[1][p][3]);
 			}
 
-			if (store_row)
+			if constexpr (U8)
+			{
+				// This wave finishes pixel row 'pair' of the slot.  Hand the other wave our two planes of
+				// ITS row, take its two planes of OUR row (double buffered, one barrier per slot; every
+				// wave of the workgroup runs the same number of slots).
+				uint4 send;
+				send.x = pack2(pair ? out[0][0][0] : out[1][0][0], pair ? out[0][0][1] : out[1][0][1]);
+				send.y = pack2(pair ? out[0][0][2] : out[1][0][2], pair ? out[0][0][3] : out[1][0][3]);
+				send.z = pack2(pair ? out[0][1][0] : out[1][1][0], pair ? out[0][1][1] : out[1][1][1]);
+				send.w = pack2(pair ? out[0][1][2] : out[1][1][2], pair ? out[0][1][3] : out[1][1][3]);
+				xbuf[K & 1][1 - pair][lane] = send;
+				__syncthreads();
+				const uint4 got = xbuf[K & 1][pair][lane];
+				const int y = 2 * r + pair;
+				if (store_row && y < oh)  // phantom last row dropped (lifting.c:112,141)
+				{
+					const uint32_t gw[4] = {got.x, got.y, got.z, got.w};
+					uint32_t px[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+					{
+						const int mine0 = pair ? out[1][0][k] : out[0][0][k];
+						const int mine1 = pair ? out[1][1][k] : out[0][1][k];
+						const int his0 = (k & 1) ? hi16(gw[k >> 1]) : lo16(gw[k >> 1]);
+						const int his1 = (k & 1) ? hi16(gw[2 + (k >> 1)]) : lo16(gw[2 + (k >> 1)]);
+						const int v0 = pair ? his0 : mine0, v1 = pair ? his1 : mine1;
+						const int v2 = pair ? mine0 : his0, v3 = pair ? mine1 : his1;
+						int rr, gg, bb;
+						color_inverse(P.color, v0, v1, v2, rr, gg, bb);
+						px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
+						        ((uint32_t)sat8(v3) << 24);
+					}
+					*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
+				}
+			}
+			else if (store_row)
 			{
 #pragma unroll
 				for (int par = 0; par < 2; par++)
 				{
 					const int y = 2 * r + par;
-					if (y >= oh)
-						continue;  // phantom last row dropped (lifting.c:112,141)
-					if constexpr (U8)
-					{
-						uint32_t px[4];
-#pragma unroll
-						for (int k = 0; k < 4; k++)
-						{
-							int rr, gg, bb;
-							color_inverse(P.color, out[par][0][k], out[par][1 % NPL][k], out[par][2 % NPL][k], rr, gg,
-							              bb);
-							px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
-							        ((uint32_t)sat8(out[par][3 % NPL][k]) << 24);
-						}
-						*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) =
-						    make_uint4(px[0], px[1], px[2], px[3]);
-					}
-					else
-					{
+					if (y < oh)
 						*reinterpret_cast<uint2*>(dst + (uint64_t)y * out_pitch) =
 						    make_uint2(pack2(out[par][0][0], out[par][0][1]), pack2(out[par][0][2], out[par][0][3]));
-					}
 				}
 			}
 		});
@@ -773,9 +803,10 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 template <int KIND, int NPL, bool U8>
 __global__ __launch_bounds__(THREADS) void k_inverse_stream(const LevelParams P, const StreamGeom G)
 {
+	__shared__ uint4 xbuf[2][2][64];  // U8 only: [slot parity][destination wave of the pair][lane]
 	const UnitId id = decode_unit(P, G);
 	if (!id.valid)
-		return;
+		return;  // U8: units come in pairs and the workgroup is one pair, so both waves leave together
 	const int lane = threadIdx.x & 63;
 	const LaneCols lc = lane_columns(id.strip, lane, (int)P.sub_w, P.wrap);
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
@@ -783,16 +814,16 @@ __global__ __launch_bounds__(THREADS) void k_inverse_stream(const LevelParams P,
 	if (lc.hedge)
 	{
 		if (vedge)
-			inverse_stream_body<KIND, NPL, U8, true, true>(P, G, id, lc, lane);
+			inverse_stream_body<KIND, NPL, U8, true, true>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, NPL, U8, true, false>(P, G, id, lc, lane);
+			inverse_stream_body<KIND, NPL, U8, true, false>(P, G, id, lc, lane, xbuf);
 	}
 	else
 	{
 		if (vedge)
-			inverse_stream_body<KIND, NPL, U8, false, true>(P, G, id, lc, lane);
+			inverse_stream_body<KIND, NPL, U8, false, true>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, NPL, U8, false, false>(P, G, id, lc, lane);
+			inverse_stream_body<KIND, NPL, U8, false, false>(P, G, id, lc, lane, xbuf);
 	}
 }
 
