@@ -7,6 +7,7 @@
 // on the host.
 #include "ako_kernels.hip.h"
 #include "ako_stream.hip.h"
+#include "ako_tail.hip.h"
 
 #include "../../include/ako_hip.h"
 
@@ -284,7 +285,7 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 		return false;
 	if (mode == PATH_STREAM)
 		return true;
-	return L.tw >= 64 && L.th >= 32;
+	return L.tw >= 64 && L.th >= 24;
 }
 
 StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
@@ -296,14 +297,17 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
 		seg_rows = (uint32_t)atoi(e);
 	if (seg_rows == 0)
 	{
-		// aim at ~8192 waves per launch (256 CUs x 8 waves x 4 rounds); 6 halo slots per segment
+		// aim at ~8192 waves per launch (256 CUs x 8 waves x 4 rounds).  Every segment re-reads 6 halo
+		// row slots, so big levels keep segments of >= 24 rows; small levels are latency bound
+		// (a wave's row slots are a dependent chain) and prefer many short segments
 		const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
 		uint64_t segs = (8192 + per_seg - 1) / per_seg;
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
-		if (seg_rows < 32)
-			seg_rows = 32;
+		const uint32_t floor_rows = (L.tw >= 1024) ? 24 : 12;
+		if (seg_rows < floor_rows)
+			seg_rows = floor_rows;
 	}
 	if (seg_rows > L.th)
 		seg_rows = L.th;
@@ -358,6 +362,78 @@ uint64_t scratch_plane_elems(const Group& g, int which)
 	return (uint64_t)g.levels[which].tw * g.levels[which].th;
 }
 
+// first level handled by the fused in-LDS tail kernel (nl = none).  Level 0 of a u8 image never is.
+size_t tail_start(const akoHipPlan* pl, const Group& g)
+{
+	const char* e = getenv("AKO_HIP_TAIL");
+	const size_t nl = g.levels.size();
+	if (e != nullptr && atoi(e) == 0)
+		return nl;
+	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
+	for (size_t l = planes ? 0 : 1; l < nl; l++)
+		if (g.levels[l].cw <= (uint32_t)TAIL_MAX && g.levels[l].ch <= (uint32_t)TAIL_MAX)
+			return (nl - l <= (size_t)TAIL_LEVELS) ? l : nl;
+	return nl;
+}
+
+int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int16_t* d_streams)
+{
+	const Group& g = pl->groups[gi];
+	const size_t nl = g.levels.size();
+	TailParams T;
+	memset(&T, 0, sizeof T);
+	T.nlev = (uint32_t)(nl - lt);
+	uint64_t samples = 0;
+	for (size_t l = lt; l < nl; l++)
+	{
+		const LevelGeom& L = g.levels[l];
+		TailLevel& t = T.lv[l - lt];
+		t.cw = L.cw, t.ch = L.ch, t.tw = L.tw, t.th = L.th, t.kind = L.kind;
+		for (int m = 0; m < 2; m++)
+		{
+			t.q[m] = L.q[m], t.g[m] = L.g[m];
+			t.rq[m] = (float)((1.0 / (double)(L.q[m] < 1 ? 1 : L.q[m])) * (1.0 + 1e-6));
+		}
+		t.grp0 = L.grp_off[0];
+		t.gsize = 1 + 3 * L.tw * L.th;
+		samples += (uint64_t)L.cw * L.ch;
+	}
+	T.wrap = (int)pl->s.wrap;
+	T.channels = (uint32_t)pl->channels;
+	T.tiles = g.d_tiles, T.n_tiles = (uint32_t)g.tiles.size(), T.batch = (uint32_t)pl->batch;
+	T.stream = d_streams, T.stream_stride = pl->stream_values;
+	T.fw = g.fw, T.fh = g.fh;
+	if (lt == 0)
+	{
+		// PLANES_I16 mode, small tile: the planes themselves are the input / output
+		T.plane = (int16_t*)d_images;
+		T.plane_tiled = 1;
+		T.plane_pitch = (uint32_t)pl->w;
+		T.plane_plane_stride = (uint64_t)pl->w * pl->h;
+		T.plane_inst_stride = T.plane_plane_stride * pl->channels;
+	}
+	else
+	{
+		const int which = (int)((lt - 1) & 1);  // LL of level lt-1
+		T.plane = pl->scratch[which];
+		T.plane_pitch = g.levels[lt].cw;
+		T.plane_plane_stride = scratch_plane_elems(g, which);
+		T.plane_inst_stride = T.plane_plane_stride * pl->channels;
+	}
+	const uint64_t blocks = (uint64_t)g.tiles.size() * pl->batch * pl->channels;
+	if (int rc = check_blocks(blocks))
+		return rc;
+	Launch LA{pl, decode};
+	if (int rc = LA.begin())
+		return rc;
+	if (decode)
+		hipLaunchKernelGGL(k_inverse_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), TAIL_LDS_BYTES, pl->stream, T);
+	else
+		hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), TAIL_LDS_BYTES, pl->stream, T);
+	const uint64_t units = samples * blocks;
+	return LA.end(decode ? "inv_tail" : "fwd_tail", (uint32_t)lt, (uint32_t)gi, units, units * 2, units * 2);
+}
+
 int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream)
 {
 	const Group& g = pl->groups[gi];
@@ -402,8 +478,9 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			return fail(AKO_ERROR, "tile with an extent <= 2 cannot be encoded (reference mis-reads it: lifting.c:285)%s%s");
 
 		const size_t nl = g.levels.size();
+		const size_t lt = tail_start(pl, g);
 		const uint64_t insts = (uint64_t)g.tiles.size() * pl->batch;
-		for (size_t l = 0; l < nl; l++)
+		for (size_t l = 0; l < lt; l++)
 		{
 			const LevelGeom& L = g.levels[l];
 			LevelParams P;
@@ -489,6 +566,9 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			if (int rc = LA.end(name, (uint32_t)l, (uint32_t)gi, samples, samples * (u8 ? 1 : 2), outs * 2))
 				return rc;
 		}
+		if (lt < nl)
+			if (int rc = run_tail(pl, (int)gi, lt, 0, (void*)d_images, (int16_t*)d_streams))
+				return rc;
 	}
 	return 0;
 }
@@ -509,8 +589,12 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 		}
 
 		const size_t nl = g.levels.size();
+		const size_t lt = tail_start(pl, g);
 		const uint64_t insts = (uint64_t)g.tiles.size() * pl->batch;
-		for (size_t l = nl; l-- > 0;)
+		if (lt < nl)
+			if (int rc = run_tail(pl, (int)gi, lt, 1, d_images, (int16_t*)d_streams))
+				return rc;
+		for (size_t l = lt; l-- > 0;)
 		{
 			const LevelGeom& L = g.levels[l];
 			LevelParams P;

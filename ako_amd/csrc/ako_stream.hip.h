@@ -58,11 +58,11 @@ constexpr int SWAVES = THREADS / 64;
 // lane i <- lane i-1 / lane i+1 over the whole wave64 (gfx9 DPP wave shifts)
 __device__ __forceinline__ int from_prev_lane(int x)
 {
-	return __builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	return __builtin_amdgcn_mov_dpp(x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 __device__ __forceinline__ int from_next_lane(int x)
 {
-	return __builtin_amdgcn_update_dpp(0, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+	return __builtin_amdgcn_mov_dpp(x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 
 template <bool NARROW>
@@ -71,24 +71,48 @@ __device__ __forceinline__ int nrw(int v)
 	return NARROW ? (int)(int16_t)v : v;
 }
 
-// lifting terms (wavelet-dd137.c:36-54, wavelet-cdf53.c:36-54); P = predict-like, U = update-like
-template <int KIND>
-__device__ __forceinline__ int term_p(int l1, int e, int p1, int p2)
+// Lifting arithmetic (wavelet-dd137.c:36-54, wavelet-cdf53.c:36-54, wavelet-haar.c:41,68).
+// A step is  base +/- trunc(sum / 2^k)  narrowed to int16.  With bias = (sum < 0) ? 2^k - 1 : 0,
+//   base + trunc(sum / 2^k) == ((base << k) + sum + bias) >> k        (arithmetic shift)
+// which costs: sign bit, shift-add, multiply-add (24 bit), bit-field extract (shift + int16 wrap).
+// Subtraction is done by negating the sum (trunc is odd): base - trunc(s / 2^k) = base + trunc(-s / 2^k).
+template <bool NARROW>
+__device__ __forceinline__ int lift_add(int base, int sum, int k)
+{
+	const int neg = (int)((unsigned)sum >> 31);
+	const int x = (base << k) + sum + __mul24(neg, (1 << k) - 1);
+	return NARROW ? (int)(int16_t)(x >> k) : (x >> k);
+}
+
+// predict-like sum from the even taps l1 = c-1, e = c, p1 = c+1, p2 = c+2; SGN = -1 gives the negated sum
+template <int KIND, int SGN>
+__device__ __forceinline__ int sum_p(int l1, int e, int p1, int p2)
 {
 	if (KIND == K_DD137)
-		return tdiv(l1 + p2 - 9 * (e + p1), 4);
+		return (SGN > 0) ? (l1 + p2 + __mul24(e + p1, -9)) : (__mul24(e + p1, 9) - (l1 + p2));
 	if (KIND == K_CDF53)
-		return -tdiv(e + p1, 1);
-	return -e;
+		return (SGN > 0) ? -(e + p1) : (e + p1);
+	return (SGN > 0) ? -e : e;
+}
+// update-like sum from the high-pass taps l2 = c-2, l1 = c-1, h = c, p1 = c+1
+template <int KIND, int SGN>
+__device__ __forceinline__ int sum_u(int l2, int l1, int h, int p1)
+{
+	if (KIND == K_DD137)
+		return (SGN > 0) ? (__mul24(l1 + h, 9) - (l2 + p1)) : (l2 + p1 + __mul24(l1 + h, -9));
+	if (KIND == K_CDF53)
+		return (SGN > 0) ? (l1 + h) : -(l1 + h);
+	return 0;
 }
 template <int KIND>
-__device__ __forceinline__ int term_u(int l2, int l1, int h, int p1)
+constexpr int shift_p()
 {
-	if (KIND == K_DD137)
-		return tdiv(-l2 - p1 + 9 * (l1 + h), 5);
-	if (KIND == K_CDF53)
-		return tdiv(l1 + h, 2);
-	return 0;
+	return KIND == K_DD137 ? 4 : (KIND == K_CDF53 ? 1 : 0);
+}
+template <int KIND>
+constexpr int shift_u()
+{
+	return KIND == K_DD137 ? 5 : (KIND == K_CDF53 ? 2 : 0);
 }
 
 // what a lane needs to know about the left / right tile border
@@ -141,8 +165,8 @@ __device__ __forceinline__ void hlift_forward(int E0, int O0, int E1, int O1, co
 	int p2_0 = eR0, p2_1 = eR1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.last)
 		p2_0 = eL, p2_1 = E0;  // far tap := opposite near tap
-	H0 = nrw<NARROW>(O0 + term_p<KIND>(eL, E0, E1, p2_0));
-	H1 = nrw<NARROW>(O1 + term_p<KIND>(E0, E1, eR0, p2_1));
+	H0 = lift_add<NARROW>(O0, sum_p<KIND, +1>(eL, E0, E1, p2_0), shift_p<KIND>());
+	H1 = lift_add<NARROW>(O1, sum_p<KIND, +1>(E0, E1, eR0, p2_1), shift_p<KIND>());
 
 	if (HEDGE)
 		fix_halo_lanes(H0, H1, ed);
@@ -154,8 +178,8 @@ __device__ __forceinline__ void hlift_forward(int E0, int O0, int E1, int O1, co
 	int l2_0 = hL0, l2_1 = hL1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.first)
 		l2_0 = H1, l2_1 = hR0;
-	L0 = nrw<NARROW>(E0 + term_u<KIND>(l2_0, hL1, H0, H1));
-	L1 = nrw<NARROW>(E1 + term_u<KIND>(l2_1, H0, H1, hR0));
+	L0 = lift_add<NARROW>(E0, sum_u<KIND, +1>(l2_0, hL1, H0, H1), shift_u<KIND>());
+	L1 = lift_add<NARROW>(E1, sum_u<KIND, +1>(l2_1, H0, H1, hR0), shift_u<KIND>());
 }
 
 // Horizontal inverse lift of one row: (L0 L1 H0 H1) -> samples (E0 O0 E1 O1).  Valid in lanes 2..61.
@@ -179,8 +203,8 @@ __device__ __forceinline__ void hlift_inverse(int L0, int L1, int H0, int H1, co
 	int l2_0 = hL0, l2_1 = hL1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.first)
 		l2_0 = H1, l2_1 = hR0;
-	E0 = nrw<true>(L0 - term_u<KIND>(l2_0, hL1, H0, H1));
-	E1 = nrw<true>(L1 - term_u<KIND>(l2_1, H0, H1, hR0));
+	E0 = lift_add<true>(L0, sum_u<KIND, -1>(l2_0, hL1, H0, H1), shift_u<KIND>());
+	E1 = lift_add<true>(L1, sum_u<KIND, -1>(l2_1, H0, H1, hR0), shift_u<KIND>());
 
 	if (HEDGE)
 		fix_halo_lanes(E0, E1, ed);
@@ -192,8 +216,8 @@ __device__ __forceinline__ void hlift_inverse(int L0, int L1, int H0, int H1, co
 	int p2_0 = eR0, p2_1 = eR1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.last)
 		p2_0 = eL, p2_1 = E0;
-	O0 = nrw<true>(H0 - term_p<KIND>(eL, E0, E1, p2_0));
-	O1 = nrw<true>(H1 - term_p<KIND>(E0, E1, eR0, p2_1));
+	O0 = lift_add<true>(H0, sum_p<KIND, -1>(eL, E0, E1, p2_0), shift_p<KIND>());
+	O1 = lift_add<true>(H1, sum_p<KIND, -1>(E0, E1, eR0, p2_1), shift_p<KIND>());
 }
 
 // ---- vertical pipelines ---------------------------------------------------------------------
@@ -222,7 +246,7 @@ __device__ __forceinline__ void vstep_forward(VFwd& s, int E, int O, int v, int 
 	int p2 = E;
 	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && u + 2 >= T)
 		p2 = eA;
-	int H = nrw < NARROW || KIND == K_HAAR > (oA + term_p<KIND>(eA, eB, eC, p2));
+	int H = lift_add < NARROW || KIND == K_HAAR > (oA, sum_p<KIND, +1>(eA, eB, eC, p2), shift_p<KIND>());
 	if (VEDGE && KIND != K_HAAR && wrap != W_REPEAT)
 	{
 		if (u >= T)
@@ -235,7 +259,7 @@ __device__ __forceinline__ void vstep_forward(VFwd& s, int E, int O, int v, int 
 	int l2 = hA;
 	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && r < 2)
 		l2 = H;
-	lp_out = nrw<NARROW>(eA + term_u<KIND>(l2, hB, hC, H));
+	lp_out = lift_add<NARROW>(eA, sum_u<KIND, +1>(l2, hB, hC, H), shift_u<KIND>());
 	hp_out = hC;
 	eA = E, oA = O, hA = H;
 }
@@ -262,7 +286,7 @@ __device__ __forceinline__ void vstep_inverse(VInv& s, int LP, int HP, int v, in
 	int l2 = hA;
 	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && re < 2)
 		l2 = HP;
-	int Ev = nrw<true>(s.l - term_u<KIND>(l2, hB, hC, HP));
+	int Ev = lift_add<true>(s.l, sum_u<KIND, -1>(l2, hB, hC, HP), shift_u<KIND>());
 	if (VEDGE && KIND != K_HAAR && wrap != W_REPEAT)
 	{
 		if (re >= T)
@@ -276,7 +300,7 @@ __device__ __forceinline__ void vstep_inverse(VInv& s, int LP, int HP, int v, in
 	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && ro + 2 >= T)
 		p2 = eA;
 	even_out = eB;
-	odd_out = nrw<true>(hA - term_p<KIND>(eA, eB, eC, p2));
+	odd_out = lift_add<true>(hA, sum_p<KIND, -1>(eA, eB, eC, p2), shift_p<KIND>());
 	hA = HP, s.l = LP, eA = Ev;
 }
 
@@ -295,7 +319,10 @@ struct UnitId
 __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const StreamGeom& G)
 {
 	UnitId id;
-	uint64_t u = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	// the wave index is wave-uniform, but the compiler only knows that after a readfirstlane: with it,
+	// strip / segment / plane and every base address derived from them live in SGPRs
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	uint64_t u = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
 	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
 	id.valid = u < total;
 	id.pg = (uint32_t)(u % P.plane_groups);
@@ -385,6 +412,76 @@ __device__ __forceinline__ void color_forward_pair(int color, int pair, int r, i
 	color_forward(color, r, g, b, c0, c1, c2);
 	v0 = pair ? c2 : c0;
 	v1 = pair ? a : c1;
+}
+
+// Four RGBA pixels -> the two planes of this wave's pair, the colour mode switch hoisted out of the
+// pixel loop (one wave-uniform branch per row instead of three per pixel).
+__device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int color, int pair, bool discard, int v0[4],
+                                                   int v1[4])
+{
+	int r[4], g[4], b[4], a[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		r[k] = px[k] & 255, g[k] = (px[k] >> 8) & 255, b[k] = (px[k] >> 16) & 255, a[k] = px[k] >> 24;
+	if (discard)  // wave-uniform; format.c:38-49
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			if (a[k] == 0)
+				r[k] = g[k] = b[k] = 0;
+	}
+	if (color == C_YCOCG || color == C_YCOCG_Q)
+	{
+		const int ysh = (color == C_YCOCG_Q) ? 1 : 0;
+		if (pair == 0)  // wave-uniform
+		{
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const int co = r[k] - b[k];
+				const int t = b[k] + tdiv(co, 1);
+				const int cg = g[k] - t;
+				v0[k] = (t + tdiv(cg, 1)) << ysh, v1[k] = co;
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const int co = r[k] - b[k];
+				const int t = b[k] + tdiv(co, 1);
+				v0[k] = g[k] - t, v1[k] = a[k];
+			}
+		}
+	}
+	else if (color == C_SUBG)
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			v0[k] = pair ? (b[k] - g[k]) : g[k];
+			v1[k] = pair ? a[k] : (r[k] - g[k]);
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			v0[k] = pair ? b[k] : r[k];
+			v1[k] = pair ? a[k] : g[k];
+		}
+	}
+}
+
+// gate + quantize on the float pipe (see quantize() in ako_kernels.hip.h for the exactness argument;
+// q == 1 needs no special case: trunc(v * fl(1 + 1e-6)) == v for |v| <= 32768)
+__device__ __forceinline__ int quantize_f(int v, float gf, float rq)
+{
+	const float f = (float)v;
+	const int r = (int)(f * rq);
+	return (fabsf(f) > gf) ? r : 0;
 }
 
 // inverse colour transform of one pixel (format.c:138-218), int16 wrap after every step
@@ -479,6 +576,8 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		for (int p = 0; p < NPL; p++)
 			tile_stream[P.grp_off[p_first + p]] = (int16_t)((p_first + p == 0) ? P.q_luma : P.q_chroma);
 
+	const float gf_luma = (float)P.g_luma, gf_chroma = (float)P.g_chroma;
+
 	VFwd st[NPL][4];
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
@@ -523,16 +622,13 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				if constexpr (U8)
 				{
 					const uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
+					int v0[4], v1[4];
+					decode_pixels_pair(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 					{
-						int r = px[k] & 255, g = (px[k] >> 8) & 255, b = (px[k] >> 16) & 255, a = px[k] >> 24;
-						if (P.discard && a == 0)
-							r = g = b = 0;
-						int v0, v1;
-						color_forward_pair(P.color, (int)id.pg, r, g, b, a, v0, v1);
-						smp[par][0][k] = zero_row ? 0 : v0;
-						smp[par][1 % NPL][k] = zero_row ? 0 : v1;
+						smp[par][0][k] = zero_row ? 0 : v0[k];
+						smp[par][1 % NPL][k] = zero_row ? 0 : v1[k];
 					}
 				}
 				else
@@ -545,7 +641,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			}
 
 			const int r = v - 3;
-			const bool store_row = (r >= r_lo) && (r < r_hi) && store_lane;
+			uint32_t w_ll[NPL], w_c[NPL], w_b[NPL], w_d[NPL];
 #pragma unroll
 			for (int p = 0; p < NPL; p++)
 			{
@@ -559,21 +655,27 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				for (int k = 0; k < 4; k++)
 					vstep_forward<KIND, NARROW, VEDGE, K>(st[p][k], e[k], o[k], v, wrap, Tr, lp[k], hp[k]);
 
-				if (store_row)
+				// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
+				const float gf = (p_first + p == 0) ? gf_luma : gf_chroma;
+				const float rq = (p_first + p == 0) ? P.rq_luma : P.rq_chroma;
+				w_ll[p] = pack2(lp[0], lp[1]);
+				w_c[p] = pack2(quantize_f(hp[0], gf, rq), quantize_f(hp[1], gf, rq));
+				w_b[p] = pack2(quantize_f(lp[2], gf, rq), quantize_f(lp[3], gf, rq));
+				w_d[p] = pack2(quantize_f(hp[2], gf, rq), quantize_f(hp[3], gf, rq));
+			}
+			if ((r >= r_lo) && (r < r_hi))  // wave-uniform
+			{
+				if (store_lane)
 				{
-					const int pl = p_first + p;
-					const int q = (pl == 0) ? P.q_luma : P.q_chroma;
-					const int g = (pl == 0) ? P.g_luma : P.g_chroma;
-					const float rq = (pl == 0) ? P.rq_luma : P.rq_chroma;
-					int16_t* grp = grp_base[p] + (uint64_t)r * Tc;
-					// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
-					*reinterpret_cast<uint32_t*>(ll_base[p] + (uint64_t)r * ll_pitch) = pack2(lp[0], lp[1]);
-					*reinterpret_cast<uint32_t*>(grp) =
-					    pack2(quantize(hp[0], q, g, rq), quantize(hp[1], q, g, rq));
-					*reinterpret_cast<uint32_t*>(grp + nsub) =
-					    pack2(quantize(lp[2], q, g, rq), quantize(lp[3], q, g, rq));
-					*reinterpret_cast<uint32_t*>(grp + 2 * nsub) =
-					    pack2(quantize(hp[2], q, g, rq), quantize(hp[3], q, g, rq));
+#pragma unroll
+					for (int p = 0; p < NPL; p++)
+					{
+						int16_t* grp = grp_base[p] + (uint64_t)r * Tc;
+						*reinterpret_cast<uint32_t*>(ll_base[p] + (uint64_t)r * ll_pitch) = w_ll[p];
+						*reinterpret_cast<uint32_t*>(grp) = w_c[p];
+						*reinterpret_cast<uint32_t*>(grp + nsub) = w_b[p];
+						*reinterpret_cast<uint32_t*>(grp + 2 * nsub) = w_d[p];
+					}
 				}
 			}
 		});

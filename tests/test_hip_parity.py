@@ -42,17 +42,21 @@ def hip_decode_body(body, s, ch, w, h):
         return d_img.cpu().numpy().reshape(h, w, ch)
 
 
-@pytest.fixture(params=["auto", "generic", "stream"])
+@pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
-    kernels wherever they are legal (even at tiny sizes), 'auto' is what ships."""
-    old = os.environ.get("AKO_HIP_PATH")
-    os.environ["AKO_HIP_PATH"] = request.param
-    yield request.param
-    if old is None:
-        os.environ.pop("AKO_HIP_PATH", None)
-    else:
-        os.environ["AKO_HIP_PATH"] = old
+    kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
+    switches the fused in-LDS tail kernel off (AKO_HIP_TAIL=0) so every level runs as its own launch."""
+    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL")}
+    mode = request.param
+    os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
+    os.environ["AKO_HIP_TAIL"] = "0" if mode.endswith("notail") else "1"
+    yield mode
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def test_device_present():
