@@ -285,7 +285,7 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 		return false;
 	if (mode == PATH_STREAM)
 		return true;
-	return L.tw >= 64 && L.th >= 24;
+	return L.tw >= 64 && L.th >= 12;
 }
 
 StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
@@ -305,7 +305,7 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
-		const uint32_t floor_rows = (L.tw >= 1024) ? 24 : 12;
+		const uint32_t floor_rows = (L.tw >= 1024) ? 24 : 6;
 		if (seg_rows < floor_rows)
 			seg_rows = floor_rows;
 	}

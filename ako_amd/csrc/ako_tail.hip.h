@@ -22,7 +22,7 @@ namespace ako
 {
 
 constexpr int TAIL_MAX = 128;     // largest level extent handled here
-constexpr int TAIL_THREADS = 512;
+constexpr int TAIL_THREADS = 1024;
 constexpr int TAIL_LEVELS = 10;
 // window of the largest tail level (sub-band extent TAIL_MAX / 2 = 64): (2 * (64 + 6)) rows of
 // 2 * (64 + 8) samples; the dense LL array holds at most 64 x 64 samples
@@ -60,18 +60,30 @@ struct TailParams
 	uint32_t fw, fh;          // final low-pass extent; plane p's low-pass sits at p * fw * fh
 };
 
+// exact idx / d for idx < 2^16, d < 2^16 with one multiply-high: M = floor(2^32 / d) + 1
+struct FastDiv
+{
+	uint32_t d, m;
+	__device__ __forceinline__ explicit FastDiv(int dd) : d((uint32_t)dd), m(dd > 1 ? (0xFFFFFFFFu / (uint32_t)dd + 1u) : 0u) {}
+	__device__ __forceinline__ int div(int idx) const
+	{
+		return (d > 1) ? (int)__umulhi((uint32_t)idx, m) : idx;
+	}
+};
+
 // The four lifting phases of one level on a window that covers the whole plane (origin slot
 // -ORG_R / -ORG_C, Tc x Tr sub-band coefficients, element pitch wp).
 template <int KIND, int SGN>
 __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, int Tr, int wrap, int tid)
 {
 	const int nrows = 2 * (Tr + 2 * ORG_R);
+	const FastDiv dA(Tc + 3), dB(Tc), dC(2 * Tc), dD(2 * (Tc + 2 * ORG_C));
 	if (SGN > 0)
 	{
 		// rows: predict over slots [-2, Tc], every window row; then update over [0, Tc)
 		for (int idx = tid; idx < nrows * (Tc + 3); idx += TAIL_THREADS)
 		{
-			const int wr = idx / (Tc + 3), jj = idx - wr * (Tc + 3);
+			const int wr = dA.div(idx), jj = idx - wr * (Tc + 3);
 			lift_step<KIND, true, +1, true>(W + wr * wp, 1, jj + 2, jj - 2, -ORG_C, Tc, wrap);
 		}
 		__syncthreads();
@@ -79,7 +91,7 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		{
 			for (int idx = tid; idx < nrows * Tc; idx += TAIL_THREADS)
 			{
-				const int wr = idx / Tc, jj = idx - wr * Tc;
+				const int wr = dB.div(idx), jj = idx - wr * Tc;
 				lift_step<KIND, false, +1, false>(W + wr * wp, 1, jj + ORG_C, jj, -ORG_C, Tc, wrap);
 			}
 			__syncthreads();
@@ -87,7 +99,7 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		// columns: predict over row slots [-2, Tr], the 2*Tc net columns; then update over [0, Tr)
 		for (int idx = tid; idx < (Tr + 3) * (2 * Tc); idx += TAIL_THREADS)
 		{
-			const int ii = idx / (2 * Tc), x = idx - ii * (2 * Tc);
+			const int ii = dC.div(idx), x = idx - ii * (2 * Tc);
 			lift_step<KIND, true, +1, true>(W + 2 * ORG_C + x, wp, ii + 1, ii - 2, -ORG_R, Tr, wrap);
 		}
 		__syncthreads();
@@ -95,7 +107,7 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		{
 			for (int idx = tid; idx < Tr * (2 * Tc); idx += TAIL_THREADS)
 			{
-				const int ii = idx / (2 * Tc), x = idx - ii * (2 * Tc);
+				const int ii = dC.div(idx), x = idx - ii * (2 * Tc);
 				lift_step<KIND, false, +1, false>(W + 2 * ORG_C + x, wp, ii + ORG_R, ii, -ORG_R, Tr, wrap);
 			}
 			__syncthreads();
@@ -109,14 +121,14 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		{
 			for (int idx = tid; idx < (Tr + 3) * ncols; idx += TAIL_THREADS)
 			{
-				const int ii = idx / ncols, x = idx - ii * ncols;
+				const int ii = dD.div(idx), x = idx - ii * ncols;
 				lift_step<KIND, false, -1, true>(W + x, wp, ii + 2, ii - 1, -ORG_R, Tr, wrap);
 			}
 			__syncthreads();
 		}
 		for (int idx = tid; idx < Tr * ncols; idx += TAIL_THREADS)
 		{
-			const int ii = idx / ncols, x = idx - ii * ncols;
+			const int ii = dD.div(idx), x = idx - ii * ncols;
 			lift_step<KIND, true, -1, false>(W + x, wp, ii + ORG_R, ii, -ORG_R, Tr, wrap);
 		}
 		__syncthreads();
@@ -125,14 +137,14 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		{
 			for (int idx = tid; idx < (2 * Tr) * (Tc + 3); idx += TAIL_THREADS)
 			{
-				const int y = idx / (Tc + 3), jj = idx - y * (Tc + 3);
+				const int y = dA.div(idx), jj = idx - y * (Tc + 3);
 				lift_step<KIND, false, -1, true>(W + (2 * ORG_R + y) * wp, 1, jj + 3, jj - 1, -ORG_C, Tc, wrap);
 			}
 			__syncthreads();
 		}
 		for (int idx = tid; idx < (2 * Tr) * Tc; idx += TAIL_THREADS)
 		{
-			const int y = idx / Tc, jj = idx - y * Tc;
+			const int y = dB.div(idx), jj = idx - y * Tc;
 			lift_step<KIND, true, -1, false>(W + (2 * ORG_R + y) * wp, 1, jj + ORG_C, jj, -ORG_C, Tc, wrap);
 		}
 		__syncthreads();
@@ -171,27 +183,43 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_forward_tail(const TailParams 
 		const int wcols = 2 * (Tc + 2 * ORG_C), wrows = 2 * (Tr + 2 * ORG_R), wp = wcols;
 
 		// ---- fill the window (halo by index map, phantom last row / column by clamping) ---------
-		for (int idx = tid; idx < wrows * wcols; idx += TAIL_THREADS)
+		// 8 elements per thread and round so that the global loads of the first level overlap
+		const FastDiv dW(wcols);
+		const int16_t* gsrc = nullptr;
+		if (l == 0)
 		{
-			const int wr = idx / wcols, wc = idx - wr * wcols;
-			const int mr = map_index((wr >> 1) - ORG_R, Tr, wrap);
-			const int mc = map_index((wc >> 1) - ORG_C, Tc, wrap);
-			int16_t s = 0;
-			if (mr >= 0 && mc >= 0)
+			gsrc = P.plane + (P.plane_tiled ? (uint64_t)image : inst) * P.plane_inst_stride +
+			       (uint64_t)p * P.plane_plane_stride;
+			if (P.plane_tiled)
+				gsrc += (uint64_t)td.y0 * P.plane_pitch + td.x0;
+		}
+		for (int base = tid; base < wrows * wcols; base += 8 * TAIL_THREADS)
+		{
+			int16_t val[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++)
 			{
-				const int y = min(2 * mr + (wr & 1), chh - 1), x = min(2 * mc + (wc & 1), cw - 1);
-				if (l != 0)
-					s = dense[y * cw + x];
-				else
+				const int idx = base + k * TAIL_THREADS;
+				val[k] = 0;
+				if (idx < wrows * wcols)
 				{
-					const int16_t* base = P.plane + (P.plane_tiled ? (uint64_t)image : inst) * P.plane_inst_stride +
-					                      (uint64_t)p * P.plane_plane_stride;
-					if (P.plane_tiled)
-						base += (uint64_t)td.y0 * P.plane_pitch + td.x0;
-					s = base[(uint64_t)y * P.plane_pitch + x];
+					const int wr = dW.div(idx), wc = idx - wr * wcols;
+					const int mr = map_index((wr >> 1) - ORG_R, Tr, wrap);
+					const int mc = map_index((wc >> 1) - ORG_C, Tc, wrap);
+					if (mr >= 0 && mc >= 0)
+					{
+						const int y = min(2 * mr + (wr & 1), chh - 1), x = min(2 * mc + (wc & 1), cw - 1);
+						val[k] = (l != 0) ? dense[y * cw + x] : gsrc[(uint64_t)y * P.plane_pitch + x];
+					}
 				}
 			}
-			W[idx] = s;
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+			{
+				const int idx = base + k * TAIL_THREADS;
+				if (idx < wrows * wcols)
+					W[idx] = val[k];
+			}
 		}
 		__syncthreads();
 
@@ -206,9 +234,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_forward_tail(const TailParams 
 		int16_t* lp_out = tile_stream + (uint64_t)p * P.fw * P.fh;
 		if (tid == 0)
 			grp[0] = (int16_t)q;
+		const FastDiv dT(Tc);
 		for (int idx = tid; idx < nsub; idx += TAIL_THREADS)
 		{
-			const int r = idx / Tc, c = idx - r * Tc;
+			const int r = dT.div(idx), c = idx - r * Tc;
 			const int16_t* cell = W + (2 * (r + ORG_R)) * wp + 2 * (c + ORG_C);
 			if (last)
 				lp_out[idx] = cell[0];
@@ -246,35 +275,53 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inverse_tail(const TailParams 
 		const int q = grp[0];
 		const int16_t* ll = (l + 1 == (int)P.nlev) ? (tile_stream + (uint64_t)p * P.fw * P.fh) : dense;
 
-		for (int idx = tid; idx < wrows * wcols; idx += TAIL_THREADS)
+		const FastDiv dW(wcols);
+		for (int base = tid; base < wrows * wcols; base += 8 * TAIL_THREADS)
 		{
-			const int wr = idx / wcols, wc = idx - wr * wcols;
-			const int mr = map_index((wr >> 1) - ORG_R, Tr, wrap);
-			const int mc = map_index((wc >> 1) - ORG_C, Tc, wrap);
-			int16_t s = 0;
-			if (mr >= 0 && mc >= 0)
+			int16_t val[8];
+			bool hp[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++)
 			{
-				const int quad = (wr & 1) * 2 + (wc & 1);  // 0 LL, 1 B, 2 C, 3 D
-				const int o = mr * Tc + mc;
-				if (quad == 0)
-					s = ll[o];
-				else
+				const int idx = base + k * TAIL_THREADS;
+				val[k] = 0, hp[k] = false;
+				if (idx < wrows * wcols)
 				{
-					const int sel = (quad == 2) ? 0 : ((quad == 1) ? 1 : 2);  // stream order C, B, D
-					const int cv = grp[1 + sel * nsub + o];
-					s = (q > 1) ? (int16_t)(cv * q) : (int16_t)cv;
+					const int wr = dW.div(idx), wc = idx - wr * wcols;
+					const int mr = map_index((wr >> 1) - ORG_R, Tr, wrap);
+					const int mc = map_index((wc >> 1) - ORG_C, Tc, wrap);
+					if (mr >= 0 && mc >= 0)
+					{
+						const int quad = (wr & 1) * 2 + (wc & 1);  // 0 LL, 1 B, 2 C, 3 D
+						const int o = mr * Tc + mc;
+						if (quad == 0)
+							val[k] = ll[o];
+						else
+						{
+							const int sel = (quad == 2) ? 0 : ((quad == 1) ? 1 : 2);  // stream order C, B, D
+							val[k] = grp[1 + sel * nsub + o];
+							hp[k] = true;
+						}
+					}
 				}
 			}
-			W[idx] = s;
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+			{
+				const int idx = base + k * TAIL_THREADS;
+				if (idx < wrows * wcols)
+					W[idx] = (hp[k] && q > 1) ? (int16_t)((int)val[k] * q) : val[k];  // lifting.c:30-40
+			}
 		}
 		__syncthreads();
 
 		tail_level_dispatch<-1>(L.kind, W, wp, Tc, Tr, wrap, tid);
 
 		// ---- the level's output: next level's LL (dense LDS), or the plane / image --------------
+		const FastDiv dO(ow);
 		for (int idx = tid; idx < ow * oh; idx += TAIL_THREADS)
 		{
-			const int y = idx / ow, x = idx - y * ow;
+			const int y = dO.div(idx), x = idx - y * ow;
 			const int16_t v = W[(2 * ORG_R + y) * wp + 2 * ORG_C + x];
 			if (l != 0)
 				dense[idx] = v;
