@@ -119,22 +119,32 @@ def cpu_baseline(workload: str):
             "decode_Mpx_s": round(w * h / t_dec / 1e6, 2)}
 
 
+def measured_traffic(workload, kernel, level):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE),
+    collected in separate rocprofv3 --pmc passes by scripts/collect_traffic.sh and stored, corrected as
+    MI355X_MICROARCH.md prescribes, in profiles/traffic.json.  null when no such measurement exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+        return t.get(workload, {}).get(f"{kernel}:{level}", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     import numpy as np
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
+    from ako_amd import dist as ad
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    rank, local_rank, world = ad.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the transform path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ad.init("nccl")  # RCCL; used for the barrier and the max-over-ranks only
 
     from ako_amd import api
     from oracle import pyoracle as po  # synthetic generators + cpu_baseline leg only
@@ -150,11 +160,11 @@ def main():
                      q=0 if planes else 16, g=0 if planes else 16, color=api.COLOR_NONE if planes else api.YCOCG)
     plan = api.Plan(s, ch, w, h, batch=batch, device=local_rank, planes_i16=planes)
 
+    seeds = ad.image_seeds(rank, batch)  # image j of rank r: 0x9E3779B9 + r * batch + j (configs[3] rule)
     if planes:
-        host = np.stack([po.gen_plane(w * h, seed=0x9E3779B9 + rank * batch + i).reshape(1, h, w)
-                         for i in range(batch)])
+        host = np.stack([po.gen_plane(w * h, seed=sd).reshape(1, h, w) for sd in seeds])
     else:
-        host = np.stack([po.gen_image(0, w, h, seed=0x9E3779B9 + rank * batch + i) for i in range(batch)])
+        host = np.stack([po.gen_image(0, w, h, seed=sd) for sd in seeds])
     d_img = torch.from_numpy(host).to(dev)
     d_str = plan.new_streams()
     d_back = plan.new_images()
@@ -163,31 +173,30 @@ def main():
         plan.encode(d_img, d_str)
         plan.decode(d_str, d_back)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # the decoded image of the warm-up must be what the oracle's round trip gives: cheap sanity via
-    # losslessness is not available (q=16), so compare encode->decode idempotence instead
-    plan.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # W untimed steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both
+    # sides; MAX over ranks.  HIP events around every kernel launch of the timed region (profiling)
+    # run on the same stream as the kernels (the current torch stream).
+    elapsed = ad.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, device=dev,
+                             before_timed=lambda: plan.set_profiling(True))
 
     enc = plan.kernel_records(False)
     dec = plan.kernel_records(True)
     plan.set_profiling(False)
+
+    # the timed work must be the real thing: rank 0 checks its first image's stream and decoded
+    # pixels against the checksums the compiled reference produced (tests/golden/checksums.json)
+    verified = None
+    if rank == 0 and not planes:
+        import zlib
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums.json")))["baseline"]
+        key = "cfg2_8192_dd137_q16g16" if args.workload == "full8192" else "cfg3_4k_image0"
+        if key in gold:
+            head = bytes([65, 107, 111, 2]) + int(w).to_bytes(4, "little") + int(h).to_bytes(4, "little") + \
+                int(3 | (0 << 4) | (0 << 6) | (3 << 8) | (2 << 10)).to_bytes(4, "little")
+            a = zlib.adler32(d_str[0].cpu().numpy().view(np.uint8), zlib.adler32(head)) & 0xFFFFFFFF
+            b = zlib.adler32(d_back[0].cpu().numpy()) & 0xFFFFFFFF
+            verified = (f"{a:08x}" == gold[key]["blob"]["adler32"]) and (f"{b:08x}" == gold[key]["decoded"]["adler32"])
+            assert verified, "bench output differs from the reference checksums"
 
     if rank == 0:
         pixels = w * h * batch
@@ -218,6 +227,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int16 storage / int32 arithmetic",
             "data": "synthetic",
+            "verified_against_reference_checksums": verified,
             "config": {"workload": {"full8192": "configs[2]: full path YCoCg_Q + DD13/7 + q16 + g16, one 8192x8192 "
                                                 "RGBA image per GPU, single tile, encode then decode, device resident",
                                     "batch4k": "configs[3] share: 8 x 3840x2160 RGBA images per GPU, DD13/7 q16 g16",
@@ -230,7 +240,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(args.workload, dom_key[0], dom_key[1]),
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": dom["bytes"],
                 "whole_step": {"algorithmic_bytes": total_alg_bytes,
@@ -246,6 +256,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
+
         dist.barrier()
         dist.destroy_process_group()
 
