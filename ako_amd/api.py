@@ -20,7 +20,7 @@ from typing import Callable, Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libako.so")
+LIB_PATH = os.environ.get("AKO_LIB_OVERRIDE") or os.path.join(HERE, "libako.so")  # override: timing experiments
 
 # enum akoWavelet / akoColor / akoWrap / akoCompression / akoStatus (include/ako.h)
 DD137, CDF53, HAAR, WAVELET_NONE = 0, 1, 2, 3

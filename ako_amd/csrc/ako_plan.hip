@@ -232,6 +232,8 @@ void fill_common(LevelParams& P, const akoHipPlan* pl, const Group& g, const Lev
 	P.q_luma = L.q[0], P.g_luma = L.g[0], P.q_chroma = L.q[1], P.g_chroma = L.g[1];
 	P.rq_luma = (float)((1.0 / (double)(L.q[0] < 1 ? 1 : L.q[0])) * (1.0 + 1e-6));
 	P.rq_chroma = (float)((1.0 / (double)(L.q[1] < 1 ? 1 : L.q[1])) * (1.0 + 1e-6));
+	if (const char* e = getenv("AKO_HIP_DBG"))
+		P.dbg = (uint32_t)atoi(e);
 }
 
 template <bool U8>
@@ -295,6 +297,9 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
 	uint32_t seg_rows = 0;
 	if (const char* e = getenv("AKO_HIP_SEG_ROWS"))
 		seg_rows = (uint32_t)atoi(e);
+	if (const char* e = getenv("AKO_HIP_SEG_ROWS_BIG"))  // tuning aid: levels with >= 1024 columns only
+		if (L.tw >= 1024)
+			seg_rows = (uint32_t)atoi(e);
 	if (seg_rows == 0)
 	{
 		// aim at ~8192 waves per launch (256 CUs x 8 waves x 4 rounds).  Every segment re-reads 6 halo
@@ -529,8 +534,10 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			char name[48];
 			if (streaming)
 			{
+				const char* split_env = getenv("AKO_HIP_U8_SPLIT");  // tuning aid: 4 = one plane per wave
+				const bool split4 = u8 && split_env != nullptr && atoi(split_env) == 4;
 				if (u8)
-					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
+					P.planes_per_wg = split4 ? 1 : 2, P.plane_groups = split4 ? 4 : 2;  // waves per RGBA strip
 				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
@@ -541,7 +548,9 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				const bool narrow = planes || l >= 2;
 				if (int rc = LA.begin())
 					return rc;
-				if (u8)
+				if (u8 && split4)
+					launch_forward_stream<1, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+				else if (u8)
 					launch_forward_stream<2, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else
 					launch_forward_stream<1, false>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);

@@ -56,6 +56,7 @@ constexpr int SORG = 4;    // lane 0 holds coefficient columns strip * SNET - SO
 constexpr int SWAVES = THREADS / 64;
 
 // lane i <- lane i-1 / lane i+1 over the whole wave64 (gfx9 DPP wave shifts)
+#ifndef AKO_EXPERIMENT_NO_DPP
 __device__ __forceinline__ int from_prev_lane(int x)
 {
 	return __builtin_amdgcn_mov_dpp(x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
@@ -64,6 +65,16 @@ __device__ __forceinline__ int from_next_lane(int x)
 {
 	return __builtin_amdgcn_mov_dpp(x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
+#else  // timing experiment only: wrong results
+__device__ __forceinline__ int from_prev_lane(int x)
+{
+	return x + 1;
+}
+__device__ __forceinline__ int from_next_lane(int x)
+{
+	return x - 1;
+}
+#endif
 
 template <bool NARROW>
 __device__ __forceinline__ int nrw(int v)
@@ -322,7 +333,15 @@ __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const Stream
 	// the wave index is wave-uniform, but the compiler only knows that after a readfirstlane: with it,
 	// strip / segment / plane and every base address derived from them live in SGPRs
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	uint64_t u = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+	// XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+	// physical block b runs on XCD b % 8.  Give every XCD a CONTIGUOUS range of logical blocks: then
+	// neighbouring strips / row segments -- which share halo reads and the partially written cache
+	// lines at strip borders -- meet in one L2.  (Placement only affects speed, never results.)
+	uint32_t blk = blockIdx.x;
+	const uint32_t per_xcd = gridDim.x >> 3;
+	if (!(P.dbg & 4) && blk < (per_xcd << 3))
+		blk = (blk & 7) * per_xcd + (blk >> 3);
+	uint64_t u = (uint64_t)blk * (blockDim.x >> 6) + wave;
 	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
 	id.valid = u < total;
 	id.pg = (uint32_t)(u % P.plane_groups);
@@ -475,6 +494,66 @@ __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int col
 	}
 }
 
+// Four RGBA pixels -> ONE plane (experimental 4-waves-per-strip forward variant)
+__device__ __forceinline__ void decode_pixels_plane(const uint32_t px[4], int color, int plane, bool discard, int v0[4])
+{
+	int r[4], g[4], b[4], a[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		r[k] = px[k] & 255, g[k] = (px[k] >> 8) & 255, b[k] = (px[k] >> 16) & 255, a[k] = px[k] >> 24;
+	if (discard)
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			if (a[k] == 0)
+				r[k] = g[k] = b[k] = 0;
+	}
+	if (plane == 3)
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			v0[k] = a[k];
+		return;
+	}
+	if (color == C_YCOCG || color == C_YCOCG_Q)
+	{
+		const int ysh = (color == C_YCOCG_Q) ? 1 : 0;
+		if (plane == 1)
+		{
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				v0[k] = r[k] - b[k];
+		}
+		else if (plane == 2)
+		{
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				v0[k] = g[k] - (b[k] + tdiv(r[k] - b[k], 1));
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const int t = b[k] + tdiv(r[k] - b[k], 1);
+				v0[k] = (t + tdiv(g[k] - t, 1)) << ysh;
+			}
+		}
+	}
+	else if (color == C_SUBG)
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			v0[k] = plane == 0 ? g[k] : (plane == 1 ? r[k] - g[k] : b[k] - g[k]);
+	}
+	else
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			v0[k] = plane == 0 ? r[k] : (plane == 1 ? g[k] : b[k]);
+	}
+}
+
 // gate + quantize on the float pipe (see quantize() in ako_kernels.hip.h for the exactness argument;
 // q == 1 needs no special case: trunc(v * fl(1 + 1e-6)) == v for |v| <= 32768)
 __device__ __forceinline__ int quantize_f(int v, float gf, float rq)
@@ -526,7 +605,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
 	const int chh = (int)P.full_h;
 	const int wrap = P.wrap;
-	const int p_first = U8 ? 2 * (int)id.pg : (int)id.pg;
+	const int p_first = (U8 && NPL == 2) ? 2 * (int)id.pg : (int)id.pg;
 	const int c0 = lc.c0;
 
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
@@ -593,10 +672,15 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		for (int par = 0; par < 2; par++)
 		{
 			const int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
-			if (U8)
-				raw.a[par] = *reinterpret_cast<const RawVec*>(img + (uint64_t)y * row_pitch);
-			else
-				raw.a[par] = *reinterpret_cast<const RawVec*>(src + (uint64_t)y * row_pitch);
+#ifdef AKO_EXPERIMENT_NO_LOADS  // timing experiment only: wrong results
+			if (y == 12345678)
+#endif
+			{
+				if (U8)
+					raw.a[par] = *reinterpret_cast<const RawVec*>(img + (uint64_t)y * row_pitch);
+				else
+					raw.a[par] = *reinterpret_cast<const RawVec*>(src + (uint64_t)y * row_pitch);
+			}
 		}
 	};
 
@@ -623,12 +707,16 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				{
 					const uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
 					int v0[4], v1[4];
-					decode_pixels_pair(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
+					if constexpr (NPL == 2)
+						decode_pixels_pair(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
+					else
+						decode_pixels_plane(px, P.color, (int)id.pg, P.discard != 0, v0);
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 					{
 						smp[par][0][k] = zero_row ? 0 : v0[k];
-						smp[par][1 % NPL][k] = zero_row ? 0 : v1[k];
+						if constexpr (NPL == 2)
+							smp[par][1][k] = zero_row ? 0 : v1[k];
 					}
 				}
 				else
@@ -671,6 +759,10 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					for (int p = 0; p < NPL; p++)
 					{
 						int16_t* grp = grp_base[p] + (uint64_t)r * Tc;
+						if (P.dbg & 1)  // timing experiment: force 4-byte aligned stream stores (wrong output)
+							grp = reinterpret_cast<int16_t*>(reinterpret_cast<uintptr_t>(grp) & ~(uintptr_t)3);
+						if (P.dbg & 2)  // timing experiment: skip the stream stores
+							continue;
 						*reinterpret_cast<uint32_t*>(ll_base[p] + (uint64_t)r * ll_pitch) = w_ll[p];
 						*reinterpret_cast<uint32_t*>(grp) = w_c[p];
 						*reinterpret_cast<uint32_t*>(grp + nsub) = w_b[p];

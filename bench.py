@@ -250,7 +250,7 @@ def main():
             },
             "kernels": [{"name": k[0], "level": k[1], "ms": round(a["ms"] / a["n"], 4),
                          "GBps": round(a["bytes"] / (a["ms"] / a["n"] * 1e-3) / 1e9, 1)}
-                        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]],
+                        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])],
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
