@@ -534,23 +534,20 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			char name[48];
 			if (streaming)
 			{
-				const char* split_env = getenv("AKO_HIP_U8_SPLIT");  // tuning aid: 4 = one plane per wave
-				const bool split4 = u8 && split_env != nullptr && atoi(split_env) == 4;
 				if (u8)
-					P.planes_per_wg = split4 ? 1 : 2, P.plane_groups = split4 ? 4 : 2;  // waves per RGBA strip
+					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
 				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
 				if (int rc = check_blocks(blocks))
 					return rc;
-				// int16 narrowing after every step can only be skipped where the worst-case growth of
-				// u8-sourced data provably stays inside int16: levels 0 and 1 ("ranges")
+				// int16 narrowing after every step is a no-op where the worst-case growth of u8-sourced
+				// data provably stays inside int16: levels 0 and 1 (|Y| <= 510 -> level 0 output <= 2953 ->
+				// level 1 output <= 17097).  Those levels run on the exact fp32 pipeline.
 				const bool narrow = planes || l >= 2;
 				if (int rc = LA.begin())
 					return rc;
-				if (u8 && split4)
-					launch_forward_stream<1, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
-				else if (u8)
+				if (u8)
 					launch_forward_stream<2, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else
 					launch_forward_stream<1, false>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);

@@ -76,10 +76,58 @@ __device__ __forceinline__ int from_next_lane(int x)
 }
 #endif
 
+__device__ __forceinline__ float from_prev_lane(float x)
+{
+	return __int_as_float(from_prev_lane(__float_as_int(x)));
+}
+__device__ __forceinline__ float from_next_lane(float x)
+{
+	return __int_as_float(from_next_lane(__float_as_int(x)));
+}
+__device__ __forceinline__ int read_lane(int x, int lane)
+{
+	return __builtin_amdgcn_readlane(x, lane);
+}
+__device__ __forceinline__ float read_lane(float x, int lane)
+{
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+
 template <bool NARROW>
 __device__ __forceinline__ int nrw(int v)
 {
 	return NARROW ? (int)(int16_t)v : v;
+}
+
+// ---- float pipeline -------------------------------------------------------------------------
+// Where int16 narrowing is provably a no-op (forward levels 0 and 1 of u8 data, see the plan) the
+// same integer arithmetic is carried out on the fp32 pipe: every value is an integer below 2^24 and
+// every scaled sum a multiple of 2^-5 below 2^19, so each add / fma / multiply by 2^-k is exact and
+// v_trunc_f32 is C's truncating division.  6 ops per lifting step instead of 7-8, u8 -> float
+// conversion for free (v_cvt_f32_ubyteN), no int -> float conversion in front of the quantizer.
+template <bool NARROW>
+__device__ __forceinline__ float lift_add(float base, float sum, int k)
+{
+	static_assert(!NARROW, "the float pipeline cannot wrap to int16");
+	return (k == 0) ? (base + sum) : (base + __builtin_truncf(sum * (1.0f / (float)(1 << k))));
+}
+template <int KIND, int SGN>
+__device__ __forceinline__ float sum_p(float l1, float e, float p1, float p2)
+{
+	if (KIND == K_DD137)
+		return (SGN > 0) ? __builtin_fmaf(e + p1, -9.0f, l1 + p2) : (__builtin_fmaf(e + p1, 9.0f, -(l1 + p2)));
+	if (KIND == K_CDF53)
+		return (SGN > 0) ? -(e + p1) : (e + p1);
+	return (SGN > 0) ? -e : e;
+}
+template <int KIND, int SGN>
+__device__ __forceinline__ float sum_u(float l2, float l1, float h, float p1)
+{
+	if (KIND == K_DD137)
+		return (SGN > 0) ? __builtin_fmaf(l1 + h, 9.0f, -(l2 + p1)) : __builtin_fmaf(l1 + h, -9.0f, l2 + p1);
+	if (KIND == K_CDF53)
+		return (SGN > 0) ? (l1 + h) : -(l1 + h);
+	return 0.0f;
 }
 
 // Lifting arithmetic (wavelet-dd137.c:36-54, wavelet-cdf53.c:36-54, wavelet-haar.c:41,68).
@@ -138,17 +186,18 @@ struct HEdge
 
 // overwrite the out-of-range lanes of a two-column sequence (a0 = column c0, a1 = column c1) with
 // its nearest in-range value (CLAMP / MIRROR) or zero
-__device__ __forceinline__ void fix_halo_lanes(int& a0, int& a1, const HEdge& ed)
+template <typename V>
+__device__ __forceinline__ void fix_halo_lanes(V& a0, V& a1, const HEdge& ed)
 {
 	if (ed.left)
 	{
-		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(a0, ed.lane_first);
+		const V f = (ed.wrap == W_ZERO) ? (V)0 : read_lane(a0, ed.lane_first);
 		if (ed.oob_l)
 			a0 = f, a1 = f;
 	}
 	if (ed.right)
 	{
-		const int f = (ed.wrap == W_ZERO) ? 0 : __builtin_amdgcn_readlane(a1, ed.lane_last);
+		const V f = (ed.wrap == W_ZERO) ? (V)0 : read_lane(a1, ed.lane_last);
 		if (ed.oob_r)
 			a0 = f, a1 = f;
 	}
@@ -156,11 +205,10 @@ __device__ __forceinline__ void fix_halo_lanes(int& a0, int& a1, const HEdge& ed
 
 // Horizontal forward lift of one row: samples (E0 O0 E1 O1) of this lane's two coefficient
 // columns -> (L0 L1 H0 H1).  Valid in lanes 2..61.
-template <int KIND, bool NARROW, bool HEDGE>
-__device__ __forceinline__ void hlift_forward(int E0, int O0, int E1, int O1, const HEdge& ed, int& L0, int& L1,
-                                              int& H0, int& H1)
+template <int KIND, bool NARROW, bool HEDGE, typename V>
+__device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdge& ed, V& L0, V& L1, V& H0, V& H1)
 {
-	if (KIND == K_HAAR)
+	if constexpr (KIND == K_HAAR)
 	{
 		L0 = E0, L1 = E1;
 		H0 = nrw<true>(O0 - E0), H1 = nrw<true>(O1 - E1);
@@ -169,11 +217,11 @@ __device__ __forceinline__ void hlift_forward(int E0, int O0, int E1, int O1, co
 	if (HEDGE)
 		fix_halo_lanes(E0, E1, ed);
 
-	const int eR0 = from_next_lane(E0);
-	int eL = 0, eR1 = 0;
+	const V eR0 = from_next_lane(E0);
+	V eL = 0, eR1 = 0;
 	if (KIND == K_DD137)
 		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
-	int p2_0 = eR0, p2_1 = eR1;
+	V p2_0 = eR0, p2_1 = eR1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.last)
 		p2_0 = eL, p2_1 = E0;  // far tap := opposite near tap
 	H0 = lift_add<NARROW>(O0, sum_p<KIND, +1>(eL, E0, E1, p2_0), shift_p<KIND>());
@@ -182,11 +230,11 @@ __device__ __forceinline__ void hlift_forward(int E0, int O0, int E1, int O1, co
 	if (HEDGE)
 		fix_halo_lanes(H0, H1, ed);
 
-	const int hL1 = from_prev_lane(H1);
-	int hL0 = 0, hR0 = 0;
+	const V hL1 = from_prev_lane(H1);
+	V hL0 = 0, hR0 = 0;
 	if (KIND == K_DD137)
 		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
-	int l2_0 = hL0, l2_1 = hL1;
+	V l2_0 = hL0, l2_1 = hL1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.first)
 		l2_0 = H1, l2_1 = hR0;
 	L0 = lift_add<NARROW>(E0, sum_u<KIND, +1>(l2_0, hL1, H0, H1), shift_u<KIND>());
@@ -234,40 +282,40 @@ __device__ __forceinline__ void hlift_inverse(int L0, int L1, int H0, int H1, co
 // ---- vertical pipelines ---------------------------------------------------------------------
 // Rings are indexed with the unroll position K (0..5) of the row loop; all indices are constants.
 
+template <typename V>
 struct VFwd  // forward: E[v-3..v-1] in e[], O[v-2..v-1] in o[], HP[v-5..v-3] in h[]
 {
-	int e[3], o[2], h[3];
+	V e[3], o[2], h[3];
 };
 
 // Feed row slot v (even value E, odd value O); returns LP[v-3] and HP[v-3].
-template <int KIND, bool NARROW, bool VEDGE, int K>
-__device__ __forceinline__ void vstep_forward(VFwd& s, int E, int O, int v, int wrap, int T, int& lp_out,
-                                              int& hp_out)
+template <int KIND, bool NARROW, bool VEDGE, int K, typename V>
+__device__ __forceinline__ void vstep_forward(VFwd<V>& s, V E, V O, int v, int wrap, int T, V& lp_out, V& hp_out)
 {
 	// ring slots at unroll position K
-	int& eA = s.e[K % 3];        // E[v-3]   (overwritten by E[v] at the end)
-	int& eB = s.e[(K + 1) % 3];  // E[v-2]
-	int& eC = s.e[(K + 2) % 3];  // E[v-1]
-	int& oA = s.o[K % 2];        // O[v-2]   (overwritten by O[v])
-	int& hA = s.h[K % 3];        // HP[v-5]  (overwritten by HP[v-2])
-	int& hB = s.h[(K + 1) % 3];  // HP[v-4]
-	int& hC = s.h[(K + 2) % 3];  // HP[v-3]
+	V& eA = s.e[K % 3];        // E[v-3]   (overwritten by E[v] at the end)
+	V& eB = s.e[(K + 1) % 3];  // E[v-2]
+	V& eC = s.e[(K + 2) % 3];  // E[v-1]
+	V& oA = s.o[K % 2];        // O[v-2]   (overwritten by O[v])
+	V& hA = s.h[K % 3];        // HP[v-5]  (overwritten by HP[v-2])
+	V& hB = s.h[(K + 1) % 3];  // HP[v-4]
+	V& hC = s.h[(K + 2) % 3];  // HP[v-3]
 
 	const int u = v - 2, r = v - 3;
-	int p2 = E;
+	V p2 = E;
 	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && u + 2 >= T)
 		p2 = eA;
-	int H = lift_add < NARROW || KIND == K_HAAR > (oA, sum_p<KIND, +1>(eA, eB, eC, p2), shift_p<KIND>());
+	V H = lift_add<NARROW>(oA, sum_p<KIND, +1>(eA, eB, eC, p2), shift_p<KIND>());
 	if (VEDGE && KIND != K_HAAR && wrap != W_REPEAT)
 	{
 		if (u >= T)
-			H = (wrap == W_ZERO) ? 0 : hC;  // HP[T] := HP[T-1]
+			H = (wrap == W_ZERO) ? (V)0 : hC;  // HP[T] := HP[T-1]
 		if (u < 0 && wrap == W_ZERO)
 			H = 0;
 		if (u == 0 && wrap != W_ZERO)
 			hB = H, hC = H;  // HP[-2] = HP[-1] := HP[0]
 	}
-	int l2 = hA;
+	V l2 = hA;
 	if (VEDGE && KIND == K_DD137 && wrap == W_MIRROR && r < 2)
 		l2 = H;
 	lp_out = lift_add<NARROW>(eA, sum_u<KIND, +1>(l2, hB, hC, H), shift_u<KIND>());
@@ -433,34 +481,48 @@ __device__ __forceinline__ void color_forward_pair(int color, int pair, int r, i
 	v1 = pair ? a : c1;
 }
 
-// Four RGBA pixels -> the two planes of this wave's pair, the colour mode switch hoisted out of the
-// pixel loop (one wave-uniform branch per row instead of three per pixel).
-__device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int color, int pair, bool discard, int v0[4],
-                                                   int v1[4])
+// C's x / 2 (truncating) on either pipe
+__device__ __forceinline__ int half_trunc(int x)
 {
-	int r[4], g[4], b[4], a[4];
+	return tdiv(x, 1);
+}
+__device__ __forceinline__ float half_trunc(float x)
+{
+	return __builtin_truncf(x * 0.5f);
+}
+
+// Four RGBA pixels -> the two planes of this wave's pair, the colour mode switch hoisted out of the
+// pixel loop (one wave-uniform branch per row instead of three per pixel).  V = int or float.
+template <typename V>
+__device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int color, int pair, bool discard, V v0[4],
+                                                   V v1[4])
+{
+	V r[4], g[4], b[4], a[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++)
-		r[k] = px[k] & 255, g[k] = (px[k] >> 8) & 255, b[k] = (px[k] >> 16) & 255, a[k] = px[k] >> 24;
+	{
+		r[k] = (V)(px[k] & 255), g[k] = (V)((px[k] >> 8) & 255);  // float: v_cvt_f32_ubyte0..3
+		b[k] = (V)((px[k] >> 16) & 255), a[k] = (V)(px[k] >> 24);
+	}
 	if (discard)  // wave-uniform; format.c:38-49
 	{
 #pragma unroll
 		for (int k = 0; k < 4; k++)
-			if (a[k] == 0)
-				r[k] = g[k] = b[k] = 0;
+			if (a[k] == (V)0)
+				r[k] = g[k] = b[k] = (V)0;
 	}
 	if (color == C_YCOCG || color == C_YCOCG_Q)
 	{
-		const int ysh = (color == C_YCOCG_Q) ? 1 : 0;
+		const V ymul = (color == C_YCOCG_Q) ? (V)2 : (V)1;
 		if (pair == 0)  // wave-uniform
 		{
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 			{
-				const int co = r[k] - b[k];
-				const int t = b[k] + tdiv(co, 1);
-				const int cg = g[k] - t;
-				v0[k] = (t + tdiv(cg, 1)) << ysh, v1[k] = co;
+				const V co = r[k] - b[k];
+				const V t = b[k] + half_trunc(co);
+				const V cg = g[k] - t;
+				v0[k] = (t + half_trunc(cg)) * ymul, v1[k] = co;
 			}
 		}
 		else
@@ -468,8 +530,8 @@ __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int col
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 			{
-				const int co = r[k] - b[k];
-				const int t = b[k] + tdiv(co, 1);
+				const V co = r[k] - b[k];
+				const V t = b[k] + half_trunc(co);
 				v0[k] = g[k] - t, v1[k] = a[k];
 			}
 		}
@@ -494,66 +556,6 @@ __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int col
 	}
 }
 
-// Four RGBA pixels -> ONE plane (experimental 4-waves-per-strip forward variant)
-__device__ __forceinline__ void decode_pixels_plane(const uint32_t px[4], int color, int plane, bool discard, int v0[4])
-{
-	int r[4], g[4], b[4], a[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++)
-		r[k] = px[k] & 255, g[k] = (px[k] >> 8) & 255, b[k] = (px[k] >> 16) & 255, a[k] = px[k] >> 24;
-	if (discard)
-	{
-#pragma unroll
-		for (int k = 0; k < 4; k++)
-			if (a[k] == 0)
-				r[k] = g[k] = b[k] = 0;
-	}
-	if (plane == 3)
-	{
-#pragma unroll
-		for (int k = 0; k < 4; k++)
-			v0[k] = a[k];
-		return;
-	}
-	if (color == C_YCOCG || color == C_YCOCG_Q)
-	{
-		const int ysh = (color == C_YCOCG_Q) ? 1 : 0;
-		if (plane == 1)
-		{
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				v0[k] = r[k] - b[k];
-		}
-		else if (plane == 2)
-		{
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				v0[k] = g[k] - (b[k] + tdiv(r[k] - b[k], 1));
-		}
-		else
-		{
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-			{
-				const int t = b[k] + tdiv(r[k] - b[k], 1);
-				v0[k] = (t + tdiv(g[k] - t, 1)) << ysh;
-			}
-		}
-	}
-	else if (color == C_SUBG)
-	{
-#pragma unroll
-		for (int k = 0; k < 4; k++)
-			v0[k] = plane == 0 ? g[k] : (plane == 1 ? r[k] - g[k] : b[k] - g[k]);
-	}
-	else
-	{
-#pragma unroll
-		for (int k = 0; k < 4; k++)
-			v0[k] = plane == 0 ? r[k] : (plane == 1 ? g[k] : b[k]);
-	}
-}
-
 // gate + quantize on the float pipe (see quantize() in ako_kernels.hip.h for the exactness argument;
 // q == 1 needs no special case: trunc(v * fl(1 + 1e-6)) == v for |v| <= 32768)
 __device__ __forceinline__ int quantize_f(int v, float gf, float rq)
@@ -561,6 +563,20 @@ __device__ __forceinline__ int quantize_f(int v, float gf, float rq)
 	const float f = (float)v;
 	const int r = (int)(f * rq);
 	return (fabsf(f) > gf) ? r : 0;
+}
+
+__device__ __forceinline__ int quantize_f(float f, float gf, float rq)
+{
+	const int r = (int)(f * rq);  // v_cvt_i32_f32 truncates toward zero
+	return (fabsf(f) > gf) ? r : 0;
+}
+__device__ __forceinline__ int to_int(int v)
+{
+	return v;
+}
+__device__ __forceinline__ int to_int(float v)
+{
+	return (int)v;
 }
 
 // inverse colour transform of one pixel (format.c:138-218), int16 wrap after every step
@@ -657,12 +673,14 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 
 	const float gf_luma = (float)P.g_luma, gf_chroma = (float)P.g_chroma;
 
-	VFwd st[NPL][4];
+	// narrowing kernels compute on the integer pipe, the others (narrowing provably a no-op) on fp32
+	using V = std::conditional_t<NARROW, int, float>;
+	VFwd<V> st[NPL][4];
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 #pragma unroll
 		for (int k = 0; k < 4; k++)
-			st[p][k] = VFwd{{0, 0, 0}, {0, 0}, {0, 0, 0}};
+			st[p][k] = VFwd<V>{{0, 0, 0}, {0, 0}, {0, 0, 0}};
 
 	using Raw = FwdRaw<U8>;
 	using RawVec = typename Raw::vec;
@@ -699,32 +717,28 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			const Raw& raw = ring[K % 3];
 			const bool zero_row = VEDGE && (wrap == W_ZERO) && ((unsigned)v >= (unsigned)Tr);
 
-			int smp[2][NPL][4];
+			V smp[2][NPL][4];
 #pragma unroll
 			for (int par = 0; par < 2; par++)
 			{
 				if constexpr (U8)
 				{
 					const uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
-					int v0[4], v1[4];
-					if constexpr (NPL == 2)
-						decode_pixels_pair(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
-					else
-						decode_pixels_plane(px, P.color, (int)id.pg, P.discard != 0, v0);
+					V v0[4], v1[4];
+					decode_pixels_pair<V>(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 					{
-						smp[par][0][k] = zero_row ? 0 : v0[k];
-						if constexpr (NPL == 2)
-							smp[par][1][k] = zero_row ? 0 : v1[k];
+						smp[par][0][k] = zero_row ? (V)0 : v0[k];
+						smp[par][1 % NPL][k] = zero_row ? (V)0 : v1[k];
 					}
 				}
 				else
 				{
-					smp[par][0][0] = zero_row ? 0 : lo16(raw.a[par].x);
-					smp[par][0][1] = zero_row ? 0 : hi16(raw.a[par].x);
-					smp[par][0][2] = zero_row ? 0 : lo16(raw.a[par].y);
-					smp[par][0][3] = zero_row ? 0 : hi16(raw.a[par].y);
+					smp[par][0][0] = zero_row ? (V)0 : (V)lo16(raw.a[par].x);
+					smp[par][0][1] = zero_row ? (V)0 : (V)hi16(raw.a[par].x);
+					smp[par][0][2] = zero_row ? (V)0 : (V)lo16(raw.a[par].y);
+					smp[par][0][3] = zero_row ? (V)0 : (V)hi16(raw.a[par].y);
 				}
 			}
 
@@ -733,20 +747,20 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 #pragma unroll
 			for (int p = 0; p < NPL; p++)
 			{
-				int e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
-				hlift_forward<KIND, NARROW, HEDGE>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], lc.he,
-				                                   e[0], e[1], e[2], e[3]);
-				hlift_forward<KIND, NARROW, HEDGE>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], lc.he,
-				                                   o[0], o[1], o[2], o[3]);
-				int lp[4], hp[4];
+				V e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
+				hlift_forward<KIND, NARROW, HEDGE, V>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], lc.he,
+				                                      e[0], e[1], e[2], e[3]);
+				hlift_forward<KIND, NARROW, HEDGE, V>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], lc.he,
+				                                      o[0], o[1], o[2], o[3]);
+				V lp[4], hp[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++)
-					vstep_forward<KIND, NARROW, VEDGE, K>(st[p][k], e[k], o[k], v, wrap, Tr, lp[k], hp[k]);
+					vstep_forward<KIND, NARROW, VEDGE, K, V>(st[p][k], e[k], o[k], v, wrap, Tr, lp[k], hp[k]);
 
 				// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
 				const float gf = (p_first + p == 0) ? gf_luma : gf_chroma;
 				const float rq = (p_first + p == 0) ? P.rq_luma : P.rq_chroma;
-				w_ll[p] = pack2(lp[0], lp[1]);
+				w_ll[p] = pack2(to_int(lp[0]), to_int(lp[1]));
 				w_c[p] = pack2(quantize_f(hp[0], gf, rq), quantize_f(hp[1], gf, rq));
 				w_b[p] = pack2(quantize_f(lp[2], gf, rq), quantize_f(lp[3], gf, rq));
 				w_d[p] = pack2(quantize_f(hp[2], gf, rq), quantize_f(hp[3], gf, rq));
