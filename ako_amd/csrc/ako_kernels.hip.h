@@ -98,6 +98,7 @@ struct LevelParams
 	int32_t q_luma, g_luma, q_chroma, g_chroma;
 	float rq_luma, rq_chroma;  // (1/q) * (1 + 1e-6): see quantize()
 	uint32_t dbg;              // timing experiments only (AKO_HIP_DBG), 0 in production
+	int32_t* ovf_flag;         // optimistic-float inverse: set when a value may have left int16 (see ako_stream.hip.h)
 };
 
 // ---------------------------------------------------------------------------------------------

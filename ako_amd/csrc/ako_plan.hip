@@ -95,6 +95,7 @@ struct akoHipPlan
 	// host-variant staging
 	void* d_img = nullptr;
 	void* d_stream = nullptr;
+	int32_t* d_flags = nullptr;  // overflow flags of the optimistic inverse launches
 	// profiling
 	bool profiling = false;
 	std::vector<EventPair> events[2];  // [0] encode launches, [1] decode launches
@@ -340,16 +341,16 @@ void launch_forward_stream(int kind, bool narrow, const LevelParams& P, const St
 #undef AKO_FS
 }
 
-template <int NPL, bool U8>
+template <int NPL, bool U8, bool OPT>
 void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, hipStream_t st)
 {
 	const dim3 threads(U8 ? 128 : THREADS);  // U8: the workgroup is one pair of waves (LDS plane swap)
 	if (kind == K_DD137)
-		hipLaunchKernelGGL((k_inverse_stream<K_DD137, NPL, U8>), dim3(blocks), threads, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_DD137, NPL, U8, OPT>), dim3(blocks), threads, 0, st, P, G);
 	else if (kind == K_CDF53)
-		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8>), dim3(blocks), threads, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8, OPT>), dim3(blocks), threads, 0, st, P, G);
 	else
-		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8>), dim3(blocks), threads, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8, OPT>), dim3(blocks), threads, 0, st, P, G);
 }
 
 int check_blocks(uint64_t blocks)
@@ -652,13 +653,35 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
 					return rc;
+				// u8 side: optimistic fp32 launch, then the exact kernel which only works if the first one
+				// raised the overflow flag (AKO_HIP_OPT=0 runs the exact kernel alone)
+				const char* opt_env = getenv("AKO_HIP_OPT");
+				const bool optimistic = u8 && !(opt_env != nullptr && atoi(opt_env) == 0);
+				if (optimistic)
+				{
+					if (pl->d_flags == nullptr)
+						HIP_TRY(hipMalloc((void**)&pl->d_flags, 64 * sizeof(int32_t)));
+					const size_t slot = (gi * 8 + l) % 64;
+					HIP_TRY(hipMemsetAsync(pl->d_flags + slot, 0, sizeof(int32_t), pl->stream));
+					P.ovf_flag = pl->d_flags + slot;
+					Launch LO{pl, 1};
+					if (int rc = LO.begin())
+						return rc;
+					launch_inverse_stream<2, true, true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					snprintf(name, sizeof name, "inv_stream_%s_u8", kind_name(L.kind));
+					const uint64_t smp = (uint64_t)L.cw * L.ch * pl->channels * insts;
+					const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
+					if (int rc = LO.end(name, (uint32_t)l, (uint32_t)gi, smp, ins * 2, smp))
+						return rc;
+				}
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_inverse_stream<2, true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_stream<2, true, false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else
-					launch_inverse_stream<1, false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
-				snprintf(name, sizeof name, "inv_stream_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+					launch_inverse_stream<1, false, false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+				snprintf(name, sizeof name, "inv_stream_%s%s%s", kind_name(L.kind), u8 ? "_u8" : "",
+				         optimistic ? "_exact_if_flagged" : "");
 			}
 			else
 			{
@@ -846,6 +869,8 @@ void akoHipPlanDestroy(akoHipPlan* pl)
 		(void)hipFree(pl->d_img);
 	if (pl->d_stream)
 		(void)hipFree(pl->d_stream);
+	if (pl->d_flags)
+		(void)hipFree(pl->d_flags);
 	for (int d = 0; d < 2; d++)
 		for (EventPair& e : pl->events[d])
 		{
