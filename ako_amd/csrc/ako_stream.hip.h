@@ -443,12 +443,7 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, int lane, int T
 	lc.he.last = (lc.c0 == Tc - 2);
 	lc.hedge = lc.he.left || lc.he.right;
 	if (wrap == W_REPEAT)
-	{
-		int cm = lc.c0 % Tc;
-		if (cm < 0)
-			cm += Tc;
-		lc.cs = cm;
-	}
+		lc.cs = max(map_index(lc.c0, Tc, W_REPEAT) & ~1, 0);  // pairs stay together: c0 and Tc are even
 	else
 		lc.cs = min(max(lc.c0, 0), Tc - 2);
 	lc.xs = 2 * lc.cs;
