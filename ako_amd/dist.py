@@ -42,6 +42,22 @@ def image_seeds(rank: int, per_rank: int, base: int = 0x9E3779B9) -> List[int]:
     return [(base + rank * per_rank + j) & 0xFFFFFFFF for j in range(per_rank)]
 
 
+def tile_band(image_h: int, tiles_dimension: int, rank: int, world: int):
+    """Tile sharding of ONE tiled image (BASELINE configs[4]): rank r takes a contiguous band of tile
+    rows, (y0, rows).  Tiles are independent and stored in raster order (library/encode.c:115-204), so a
+    band of whole tile rows is itself a valid image whose stream is exactly that slice of the full
+    image's stream: concatenating the ranks' streams in rank order gives the stream of the whole image.
+    No collective is involved."""
+    assert tiles_dimension > 0
+    tile_rows = (image_h + tiles_dimension - 1) // tiles_dimension
+    per = (tile_rows + world - 1) // world
+    first = min(rank * per, tile_rows)
+    last = min(first + per, tile_rows)
+    y0 = first * tiles_dimension
+    y1 = min(last * tiles_dimension, image_h)
+    return y0, max(0, y1 - y0)
+
+
 def barrier(sync: Callable[[], None] | None = None):
     import torch.distributed as dist
 

@@ -10,6 +10,8 @@ encode (u8 RGBA -> coefficient stream) followed by decode (stream -> u8 RGBA).  
                       = BASELINE.json configs[2] ("Full encode path ... 8192x8192 4-ch, 1 MI355X")
   batch4k             8 images of 3840x2160 RGBA (configs[3]'s per-GPU share: 64 images / 8 GPUs)
   lift4096            one 4096x4096 int16 plane, DD13/7 lifting only (configs[1])
+  tiles16k            configs[4]: ONE 16384x16384 RGBA image, CDF5/3 lossless, tiles 256, its tile rows
+                      split over the ranks (strong scaling: total work fixed), bit-exact round trip
 
 N > 1: one process per GPU (torchrun), every rank transforms its own images (seeded by rank): the
 path shards by image with no data-path collective ("weak" scaling); torch.distributed (RCCL) is
@@ -42,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="full8192", choices=["full8192", "batch4k", "lift4096"])
+    ap.add_argument("--workload", default="full8192", choices=["full8192", "batch4k", "lift4096", "tiles16k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="steps in flight: consecutive steps alternate over this many HIP streams / buffer sets")
@@ -152,7 +154,12 @@ def main():
     from oracle import pyoracle as po  # synthetic generators + cpu_baseline leg only
 
     # ---- workload ------------------------------------------------------------------------------
-    if args.workload == "full8192":
+    band_y0 = 0
+    if args.workload == "tiles16k":
+        w, ch, batch, planes = 16384, 4, 1, False
+        band_y0, h = ad.tile_band(16384, 256, rank, world)
+        assert h > 0, "more ranks than tile rows"
+    elif args.workload == "full8192":
         w, h, ch, batch, planes = 8192, 8192, 4, 1, False
     elif args.workload == "batch4k":
         w, h, ch, batch, planes = 3840, 2160, 4, 8, False
@@ -160,6 +167,8 @@ def main():
         w, h, ch, batch, planes = 4096, 4096, 1, 1, True
     s = api.settings(wavelet=api.DD137, wrap=api.CLAMP, compression=api.COMPRESSION_NONE,
                      q=0 if planes else 16, g=0 if planes else 16, color=api.COLOR_NONE if planes else api.YCOCG)
+    if args.workload == "tiles16k":
+        s = api.settings(wavelet=api.CDF53, wrap=api.CLAMP, compression=api.COMPRESSION_NONE, q=0, g=0, tiles=256)
     # Consecutive steps are independent passes over the same input, so they are double-buffered:
     # step i runs on stream i % inflight with its own plan, stream and output buffers.  The small,
     # latency-bound levels of one step then overlap the large kernels of the next.
@@ -170,7 +179,10 @@ def main():
     plan = plans[0]
 
     seeds = ad.image_seeds(rank, batch)  # image j of rank r: 0x9E3779B9 + r * batch + j (configs[3] rule)
-    if planes:
+    if args.workload == "tiles16k":
+        # every rank generates the same image and keeps its band of tile rows
+        host = po.gen_image(0, 16384, 16384)[None, band_y0:band_y0 + h].copy()
+    elif planes:
         host = np.stack([po.gen_plane(w * h, seed=sd).reshape(1, h, w) for sd in seeds])
     else:
         host = np.stack([po.gen_image(0, w, h, seed=sd) for sd in seeds])
@@ -214,7 +226,10 @@ def main():
     # the timed work must be the real thing: rank 0 checks its first image's stream and decoded
     # pixels against the checksums the compiled reference produced (tests/golden/checksums.json)
     verified = None
-    if rank == 0 and not planes:
+    if args.workload == "tiles16k":
+        verified = bool(torch.equal(d_back, d_img))  # lossless: every rank checks its band
+        assert verified, "lossless round trip failed"
+    elif rank == 0 and not planes:
         import zlib
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums.json")))["baseline"]
         key = "cfg2_8192_dd137_q16g16" if args.workload == "full8192" else "cfg3_4k_image0"
@@ -229,6 +244,8 @@ def main():
     if rank == 0:
         pixels = w * h * batch
         value = pixels * world * args.steps / elapsed / 1e6
+        if args.workload == "tiles16k":
+            value = 16384 * 16384 * args.steps / elapsed / 1e6  # strong scaling: the whole image per step
         # ---- per-kernel table and roofline of the dominant kernel ------------------------------
         agg = {}
         for r in enc + dec:
@@ -251,7 +268,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.workload == "tiles16k" else "weak",
             "vs_baseline": None,
             "dtype": "int16 storage / int32 arithmetic",
             "data": "synthetic",
@@ -259,7 +276,9 @@ def main():
             "config": {"workload": {"full8192": "configs[2]: full path YCoCg_Q + DD13/7 + q16 + g16, one 8192x8192 "
                                                 "RGBA image per GPU, single tile, encode then decode, device resident",
                                     "batch4k": "configs[3] share: 8 x 3840x2160 RGBA images per GPU, DD13/7 q16 g16",
-                                    "lift4096": "configs[1]: DD13/7 lift + unlift of one 4096x4096 int16 plane"}[
+                                    "lift4096": "configs[1]: DD13/7 lift + unlift of one 4096x4096 int16 plane",
+                                    "tiles16k": "configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles 256, "
+                                                "tile rows split over the ranks, round trip checked bit-exact"}[
                 args.workload], "pixels_per_gpu_step": pixels, "channels": ch, "parallelism": f"images x{world}",
                        "steps_in_flight": nfl},
             "roofline": {
