@@ -146,9 +146,14 @@ def main():
 
     rank, local_rank, world = ad.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the transform path has no CPU fallback)"
+    # rehearsal aid for one-GPU boxes: AKO_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo
+    rehearse = os.environ.get("AKO_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ad.init("nccl")  # RCCL; used for the barrier and the max-over-ranks only
+    ad.init("gloo" if rehearse else "nccl")  # RCCL; used for the barrier and the max-over-ranks only
+    red_dev = None if rehearse else dev
 
     from ako_amd import api
     from oracle import pyoracle as po  # synthetic generators + cpu_baseline leg only
@@ -202,7 +207,7 @@ def main():
     # W untimed steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both
     # sides; MAX over ranks.  HIP events around every kernel launch of the timed region (profiling)
     # run on the same stream as the kernels (the current torch stream).
-    elapsed = ad.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, device=dev,
+    elapsed = ad.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, device=red_dev,
                              before_timed=lambda: [p.set_profiling(True) for p in plans])
 
     enc = [r for p in plans for r in p.kernel_records(False)]
