@@ -368,16 +368,27 @@ uint64_t scratch_plane_elems(const Group& g, int which)
 	return (uint64_t)g.levels[which].tw * g.levels[which].th;
 }
 
+// Which tail engine: 1 = window engine (lowest latency for a few planes), 2 = segment engine (about 3x the
+// throughput when a launch has many planes: tiled images, batches).  AKO_HIP_TAIL=0 / 1 / 2 forces none / one.
+int tail_engine(const akoHipPlan* pl, const Group& g)
+{
+	if (const char* e = getenv("AKO_HIP_TAIL"))
+		return atoi(e);
+	const uint64_t planes_in_launch = (uint64_t)g.tiles.size() * pl->batch * pl->channels;
+	return planes_in_launch >= 64 ? 2 : 1;
+}
+
 // first level handled by the fused in-LDS tail kernel (nl = none).  Level 0 of a u8 image never is.
 size_t tail_start(const akoHipPlan* pl, const Group& g)
 {
-	const char* e = getenv("AKO_HIP_TAIL");
 	const size_t nl = g.levels.size();
-	if (e != nullptr && atoi(e) == 0)
+	const int engine = tail_engine(pl, g);
+	if (engine == 0)
 		return nl;
+	const uint32_t lim = (engine == 2) ? (uint32_t)SEG_TAIL_MAX : (uint32_t)TAIL_MAX;
 	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
 	for (size_t l = planes ? 0 : 1; l < nl; l++)
-		if (g.levels[l].cw <= (uint32_t)TAIL_MAX && g.levels[l].ch <= (uint32_t)TAIL_MAX)
+		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim)
 			return (nl - l <= (size_t)TAIL_LEVELS) ? l : nl;
 	return nl;
 }
@@ -429,15 +440,41 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 	const uint64_t blocks = (uint64_t)g.tiles.size() * pl->batch * pl->channels;
 	if (int rc = check_blocks(blocks))
 		return rc;
+	const bool seg_engine = tail_engine(pl, g) == 2;
+	T.pitch = 2 * g.levels[lt].tw;
+	size_t lds_bytes = TAIL_LDS_BYTES;
+	if (seg_engine)
+	{
+		lds_bytes = (size_t)(2 * g.levels[lt].th) * T.pitch * sizeof(int16_t);
+		static bool raised = false;  // up to 128 KiB of the CU's 160 KiB: beyond HIP's 64 KiB default
+		if (!raised)
+		{
+			const int cap = SEG_TAIL_MAX * SEG_TAIL_MAX * 2 + 4096;
+			HIP_TRY(hipFuncSetAttribute((const void*)k_forward_tail_seg, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+			HIP_TRY(hipFuncSetAttribute((const void*)k_inverse_tail_seg, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+			raised = true;
+		}
+	}
 	Launch LA{pl, decode};
 	if (int rc = LA.begin())
 		return rc;
-	if (decode)
-		hipLaunchKernelGGL(k_inverse_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), TAIL_LDS_BYTES, pl->stream, T);
+	if (seg_engine)
+	{
+		if (decode)
+			hipLaunchKernelGGL(k_inverse_tail_seg, dim3((uint32_t)blocks), dim3(SEGT_THREADS), lds_bytes, pl->stream, T);
+		else
+			hipLaunchKernelGGL(k_forward_tail_seg, dim3((uint32_t)blocks), dim3(SEGT_THREADS), lds_bytes, pl->stream, T);
+	}
 	else
-		hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), TAIL_LDS_BYTES, pl->stream, T);
+	{
+		if (decode)
+			hipLaunchKernelGGL(k_inverse_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), lds_bytes, pl->stream, T);
+		else
+			hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), lds_bytes, pl->stream, T);
+	}
 	const uint64_t units = samples * blocks;
-	return LA.end(decode ? "inv_tail" : "fwd_tail", (uint32_t)lt, (uint32_t)gi, units, units * 2, units * 2);
+	return LA.end(decode ? (seg_engine ? "inv_tail_seg" : "inv_tail") : (seg_engine ? "fwd_tail_seg" : "fwd_tail"),
+	              (uint32_t)lt, (uint32_t)gi, units, units * 2, units * 2);
 }
 
 int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream)

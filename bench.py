@@ -10,7 +10,7 @@ encode (u8 RGBA -> coefficient stream) followed by decode (stream -> u8 RGBA).  
                       = BASELINE.json configs[2] ("Full encode path ... 8192x8192 4-ch, 1 MI355X")
   batch4k             8 images of 3840x2160 RGBA (configs[3]'s per-GPU share: 64 images / 8 GPUs)
   lift4096            one 4096x4096 int16 plane, DD13/7 lifting only (configs[1])
-  tiles16k            configs[4]: ONE 16384x16384 RGBA image, CDF5/3 lossless, tiles 256, its tile rows
+  tiles16k            configs[4]: ONE 16384x16384 RGBA image, CDF5/3 lossless, tiles 512, its tile rows
                       split over the ranks (strong scaling: total work fixed), bit-exact round trip
 
 N > 1: one process per GPU (torchrun), every rank transforms its own images (seeded by rank): the
@@ -162,7 +162,8 @@ def main():
     band_y0 = 0
     if args.workload == "tiles16k":
         w, ch, batch, planes = 16384, 4, 1, False
-        band_y0, h = ad.tile_band(16384, 256, rank, world)
+        td16k = int(os.environ.get("AKO_BENCH_TILES", "512"))  # 256 or 512: both decodable by the reference
+        band_y0, h = ad.tile_band(16384, td16k, rank, world)
         assert h > 0, "more ranks than tile rows"
     elif args.workload == "full8192":
         w, h, ch, batch, planes = 8192, 8192, 4, 1, False
@@ -173,7 +174,7 @@ def main():
     s = api.settings(wavelet=api.DD137, wrap=api.CLAMP, compression=api.COMPRESSION_NONE,
                      q=0 if planes else 16, g=0 if planes else 16, color=api.COLOR_NONE if planes else api.YCOCG)
     if args.workload == "tiles16k":
-        s = api.settings(wavelet=api.CDF53, wrap=api.CLAMP, compression=api.COMPRESSION_NONE, q=0, g=0, tiles=256)
+        s = api.settings(wavelet=api.CDF53, wrap=api.CLAMP, compression=api.COMPRESSION_NONE, q=0, g=0, tiles=td16k)
     # Consecutive steps are independent passes over the same input, so they are double-buffered:
     # step i runs on stream i % inflight with its own plan, stream and output buffers.  The small,
     # latency-bound levels of one step then overlap the large kernels of the next.
@@ -282,7 +283,7 @@ def main():
                                                 "RGBA image per GPU, single tile, encode then decode, device resident",
                                     "batch4k": "configs[3] share: 8 x 3840x2160 RGBA images per GPU, DD13/7 q16 g16",
                                     "lift4096": "configs[1]: DD13/7 lift + unlift of one 4096x4096 int16 plane",
-                                    "tiles16k": "configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles 256, "
+                                    "tiles16k": "configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles 512 (AKO_BENCH_TILES), "
                                                 "tile rows split over the ranks, round trip checked bit-exact"}[
                 args.workload], "pixels_per_gpu_step": pixels, "channels": ch, "parallelism": f"images x{world}",
                        "steps_in_flight": nfl},

@@ -42,7 +42,8 @@ def hip_decode_body(body, s, ch, w, h):
         return d_img.cpu().numpy().reshape(h, w, ch)
 
 
-@pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt"])
+@pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt",
+                        "stream-tail1", "stream-tail2"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
     kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
@@ -51,7 +52,14 @@ def path_mode(request):
     old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT")}
     mode = request.param
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
-    os.environ["AKO_HIP_TAIL"] = "0" if mode.endswith("notail") else "1"
+    # AKO_HIP_TAIL: 0 no fused tail, 1 window-engine tail, 2 segment-engine tail, unset = chosen per launch
+    os.environ.pop("AKO_HIP_TAIL", None)
+    if mode.endswith("notail"):
+        os.environ["AKO_HIP_TAIL"] = "0"
+    elif mode.endswith("tail1"):
+        os.environ["AKO_HIP_TAIL"] = "1"
+    elif mode.endswith("tail2"):
+        os.environ["AKO_HIP_TAIL"] = "2"
     os.environ["AKO_HIP_OPT"] = "0" if mode.endswith("noopt") else "1"   # optimistic fp32 inverse on / off
     yield mode
     for k, v in old.items():
