@@ -274,6 +274,14 @@ int path_mode()
 	return PATH_AUTO;
 }
 
+bool many_planes(const akoHipPlan* pl)
+{
+	uint64_t tiles = 0;
+	for (const Group& g : pl->groups)
+		tiles += g.tiles.size();
+	return tiles * pl->batch * pl->channels >= 64;
+}
+
 // streaming kernels need a level width that is a multiple of 4 (no phantom column, and an even
 // number of coefficient columns so that a lane's column pair is never split by the border);
 // in AUTO mode they are used where they pay: wide levels
@@ -287,6 +295,10 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 	if (u8 && pl->channels != 4)
 		return false;
 	if (mode == PATH_STREAM)
+		return true;
+	// a launch over many planes (tiled images, batches of tiles) fills the chip at any level size, and the
+	// register kernels do ~3x fewer instructions per sample than the in-LDS tail: stream all the way down
+	if (many_planes(pl))
 		return true;
 	return L.tw >= 64 && L.th >= 12;
 }
@@ -368,14 +380,14 @@ uint64_t scratch_plane_elems(const Group& g, int which)
 	return (uint64_t)g.levels[which].tw * g.levels[which].th;
 }
 
-// Which tail engine: 1 = window engine (lowest latency for a few planes), 2 = segment engine (about 3x the
-// throughput when a launch has many planes: tiled images, batches).  AKO_HIP_TAIL=0 / 1 / 2 forces none / one.
+// Which tail engine: 1 = window engine (default), 2 = segment engine (kept selectable: measured equal or
+// slower than 1 on every workload of bench.py).  AKO_HIP_TAIL=0 / 1 / 2 forces none / one.
 int tail_engine(const akoHipPlan* pl, const Group& g)
 {
+	(void)pl, (void)g;
 	if (const char* e = getenv("AKO_HIP_TAIL"))
 		return atoi(e);
-	const uint64_t planes_in_launch = (uint64_t)g.tiles.size() * pl->batch * pl->channels;
-	return planes_in_launch >= 64 ? 2 : 1;
+	return 1;
 }
 
 // first level handled by the fused in-LDS tail kernel (nl = none).  Level 0 of a u8 image never is.
@@ -385,7 +397,12 @@ size_t tail_start(const akoHipPlan* pl, const Group& g)
 	const int engine = tail_engine(pl, g);
 	if (engine == 0)
 		return nl;
-	const uint32_t lim = (engine == 2) ? (uint32_t)SEG_TAIL_MAX : (uint32_t)TAIL_MAX;
+	uint32_t lim = (engine == 2) ? (uint32_t)SEG_TAIL_MAX : (uint32_t)TAIL_MAX;
+	if (many_planes(pl) && path_mode() != PATH_GENERIC)
+		lim = 8;  // see stream_eligible(): only what the streaming kernels cannot take
+	if (const char* e = getenv("AKO_HIP_TAIL_MAX"))  // tuning aid: hand smaller levels only to the tail
+		if (atoi(e) >= 4 && (uint32_t)atoi(e) < lim)
+			lim = (uint32_t)atoi(e);
 	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
 	for (size_t l = planes ? 0 : 1; l < nl; l++)
 		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim)
