@@ -591,16 +591,30 @@ __device__ __forceinline__ void color_inverse(int color, int v0, int v1, int v2,
 	}
 }
 
-// inverse colour on the float pipe; 'peak' collects the magnitudes that the int16 reference wraps
-__device__ __forceinline__ void color_inverse_f(int color, float v0, float v1, float v2, float& r, float& g, float& b,
-                                                float& peak)
+__device__ __forceinline__ uint32_t sat8f(float v)
+{
+	return (uint32_t)(int)__builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
+}
+// four integer-valued floats -> one RGBA pixel, each clamped to 0..255: v_cvt_pk_u8_f32 converts,
+// saturates and inserts the byte in one instruction (vs. clamp + convert + shift-or per channel)
+__device__ __forceinline__ uint32_t pixel_u8x4(float r, float g, float b, float a)
+{
+	uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(r, 0, 0);
+	w = __builtin_amdgcn_cvt_pk_u8_f32(g, 1, w);
+	w = __builtin_amdgcn_cvt_pk_u8_f32(b, 2, w);
+	return __builtin_amdgcn_cvt_pk_u8_f32(a, 3, w);
+}
+// acc = max(acc, |a|, |b|) in one instruction (fmaxf() would first canonicalise each operand)
+__device__ __forceinline__ void absmax3(float& acc, float a, float b)
+{
+	asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(acc) : "v"(a), "v"(b));
+}
+// inverse colour on the float pipe, intermediates untracked (the caller bounds them through its inputs)
+__device__ __forceinline__ void color_inverse_fast(int color, float v0, float v1, float v2, float& r, float& g, float& b)
 {
 	r = v0, g = v1, b = v2;
 	if (color == C_SUBG)
-	{
 		r = v1 + v0, g = v0, b = v2 + v0;
-		peak = fmaxf(peak, fmaxf(fabsf(r), fabsf(b)));
-	}
 	else if (color != C_NONE)
 	{
 		const float yv = (color == C_YCOCG_Q) ? half_trunc(v0) : v0;
@@ -608,13 +622,7 @@ __device__ __forceinline__ void color_inverse_f(int color, float v0, float v1, f
 		g = v2 + t;
 		b = t - half_trunc(v1);
 		r = b + v1;
-		peak = fmaxf(peak, fmaxf(fabsf(t), fabsf(g)));
-		peak = fmaxf(peak, fmaxf(fabsf(b), fabsf(r)));
 	}
-}
-__device__ __forceinline__ uint32_t sat8f(float v)
-{
-	return (uint32_t)(int)__builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -856,18 +864,21 @@ struct InvRaw
 //   * M = max |input| over everything the wave loads (LL and the de-quantized C, B, D, halo included);
 //     one inverse 1-D pass grows magnitudes by at most 3.03x (E <= M + 20M/32, O <= M + 20*1.625M/16),
 //     two passes by 9.2x, so M <= 3560 bounds every lifting intermediate below 32768
-//   * the colour inverse's intermediates are tracked directly
+//   * Mo = max |lifted sample| over the wave's own planes; the colour inverse (format.c:138-218) grows
+//     magnitudes by at most 3x (t <= 1.5 Mo, g <= 2.5 Mo, b <= 2 Mo, r <= 3 Mo), so Mo <= 10921 bounds its
+//     intermediates below 32768; the two waves of a pair cover the four planes between them
 // If either test fails anywhere the wave raises P.ovf_flag and the exact kernel, launched right behind
 // on the same stream, redoes the level (it returns at once when the flag is clear).
 constexpr float OPT_INPUT_BOUND = 3560.0f;
+constexpr float OPT_OUTPUT_BOUND = 10921.0f;
 
 template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE>
 __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
-                                                    const LaneCols& lc, int lane, uint4 (*xbuf)[2][64])
+                                                    const LaneCols& lc, int lane, uint4 (*xbuf)[2][2][64])
 {
 	static_assert(!OPT || U8, "the optimistic pipeline is used on the u8 side only");
 	using V = std::conditional_t<OPT, float, int>;
-	float peak_in = 0.0f, peak_col = 0.0f;
+	float peak_in = 0.0f, peak_out = 0.0f;
 	const TileDesc td = P.tiles[id.tile];
 	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
@@ -995,8 +1006,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 #pragma unroll
 					for (int k = 0; k < 4; k += 2)
 					{
-						peak_in = fmaxf(peak_in, fmaxf(fabsf((float)lpv[k]), fabsf((float)lpv[k + 1])));
-						peak_in = fmaxf(peak_in, fmaxf(fabsf((float)hpv[k]), fabsf((float)hpv[k + 1])));
+						absmax3(peak_in, (float)lpv[k], (float)lpv[k + 1]);
+						absmax3(peak_in, (float)hpv[k], (float)hpv[k + 1]);
 					}
 				}
 				if (zero_row)
@@ -1015,21 +1026,78 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				                              out[1][p][3]);
 			}
 
-			if constexpr (U8)
+			if constexpr (U8 && OPT)
 			{
 				// This wave finishes pixel row 'pair' of the slot.  Hand the other wave our two planes of
 				// ITS row, take its two planes of OUR row (double buffered, one barrier per slot; every
-				// wave of the workgroup runs the same number of slots).
+				// wave of the workgroup runs the same number of slots).  The pair index is wave-uniform:
+				// both roles are spelled out so that no per-value select is left, and floats travel as
+				// they are (no convert / pack / unpack around the LDS hop).
+#pragma unroll
+				for (int par = 0; par < 2; par++)
+#pragma unroll
+					for (int pp = 0; pp < NPL; pp++)
+					{
+						absmax3(peak_out, out[par][pp][0], out[par][pp][1]);
+						absmax3(peak_out, out[par][pp][2], out[par][pp][3]);
+					}
+				auto as_u4 = [](const float* f) {
+					return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+				};
+				if (pair)
+				{
+					xbuf[K & 1][0][0][lane] = as_u4(out[0][0]);
+					xbuf[K & 1][0][1][lane] = as_u4(out[0][1]);
+				}
+				else
+				{
+					xbuf[K & 1][1][0][lane] = as_u4(out[1][0]);
+					xbuf[K & 1][1][1][lane] = as_u4(out[1][1]);
+				}
+				__syncthreads();
+				const int y = 2 * r + pair;
+				if (store_row && y < oh)  // phantom last row dropped (lifting.c:112,141)
+				{
+					const uint4 g0 = xbuf[K & 1][pair][0][lane], g1 = xbuf[K & 1][pair][1][lane];
+					const float his0[4] = {__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)};
+					const float his1[4] = {__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)};
+					uint32_t px[4];
+					if (pair)
+					{
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+						{
+							float rr, gg, bb;
+							color_inverse_fast(P.color, his0[k], his1[k], out[1][0][k], rr, gg, bb);
+							px[k] = pixel_u8x4(rr, gg, bb, out[1][1][k]);
+						}
+					}
+					else
+					{
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+						{
+							float rr, gg, bb;
+							color_inverse_fast(P.color, out[0][0][k], out[0][1][k], his0[k], rr, gg, bb);
+							px[k] = pixel_u8x4(rr, gg, bb, his1[k]);
+						}
+					}
+					*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
+				}
+			}
+			else if constexpr (U8)
+			{
+				// exact pipe: same exchange, int16 pairs
 				uint4 send;
 				send.x = pack2(to_int(pair ? out[0][0][0] : out[1][0][0]), to_int(pair ? out[0][0][1] : out[1][0][1]));
 				send.y = pack2(to_int(pair ? out[0][0][2] : out[1][0][2]), to_int(pair ? out[0][0][3] : out[1][0][3]));
 				send.z = pack2(to_int(pair ? out[0][1][0] : out[1][1][0]), to_int(pair ? out[0][1][1] : out[1][1][1]));
 				send.w = pack2(to_int(pair ? out[0][1][2] : out[1][1][2]), to_int(pair ? out[0][1][3] : out[1][1][3]));
-				xbuf[K & 1][1 - pair][lane] = send;
+				xbuf[K & 1][1 - pair][0][lane] = send;
 				__syncthreads();
-				const uint4 got = xbuf[K & 1][pair][lane];
+				const uint4 got = xbuf[K & 1][pair][0][lane];
 				const int y = 2 * r + pair;
-				if (store_row && y < oh)  // phantom last row dropped (lifting.c:112,141)
+				if (store_row && y < oh)
 				{
 					const uint32_t gw[4] = {got.x, got.y, got.z, got.w};
 					uint32_t px[4];
@@ -1042,19 +1110,10 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						const V his1 = (V)((k & 1) ? hi16(gw[2 + (k >> 1)]) : lo16(gw[2 + (k >> 1)]));
 						const V v0 = pair ? his0 : mine0, v1 = pair ? his1 : mine1;
 						const V v2 = pair ? mine0 : his0, v3 = pair ? mine1 : his1;
-						if constexpr (OPT)
-						{
-							float rr, gg, bb;
-							color_inverse_f(P.color, v0, v1, v2, rr, gg, bb, peak_col);
-							px[k] = sat8f(rr) | (sat8f(gg) << 8) | (sat8f(bb) << 16) | (sat8f(v3) << 24);
-						}
-						else
-						{
-							int rr, gg, bb;
-							color_inverse(P.color, v0, v1, v2, rr, gg, bb);
-							px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
-							        ((uint32_t)sat8(v3) << 24);
-						}
+						int rr, gg, bb;
+						color_inverse((int)P.color, (int)v0, (int)v1, (int)v2, rr, gg, bb);
+						px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
+						        ((uint32_t)sat8((int)v3) << 24);
 					}
 					*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
 				}
@@ -1075,7 +1134,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	}
 	if constexpr (OPT)
 	{
-		const bool bad = !(peak_in <= OPT_INPUT_BOUND) || !(peak_col < 32768.0f);  // negated: NaN counts as bad
+		const bool bad = !(peak_in <= OPT_INPUT_BOUND) || !(peak_out <= OPT_OUTPUT_BOUND);  // negated: NaN counts as bad
 		if (__any(bad) && lane == 0)
 			atomicOr(P.ovf_flag, 1);
 	}
@@ -1084,7 +1143,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 template <int KIND, int NPL, bool U8, bool OPT>
 __global__ __launch_bounds__(THREADS) void k_inverse_stream(const LevelParams P, const StreamGeom G)
 {
-	__shared__ uint4 xbuf[2][2][64];  // U8 only: [slot parity][destination wave of the pair][lane]
+	__shared__ uint4 xbuf[2][2][2][64];  // U8 only: [slot parity][destination wave of the pair][plane][lane]
 	if (!OPT && P.ovf_flag != nullptr)
 	{
 		// exact re-run behind an optimistic launch: nothing to do unless that launch raised the flag
