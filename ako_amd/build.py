@@ -48,6 +48,7 @@ def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
             # about two plain adds on gfx950 (MI355X_MICROARCH.md, cycle constants) and needs register pairs
             _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                   "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"] + (extra_hip_flags or []) +
+                 os.environ.get("AKO_HIPCC_EXTRA", "").split() +  # experiments only
                  ["-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     c_deps = [os.path.join(CSRC, h) for h in C_HEADERS]

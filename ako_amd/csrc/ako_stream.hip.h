@@ -394,6 +394,11 @@ __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const Stream
 	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
 	id.valid = u < total;
 	id.pg = (uint32_t)(u % P.plane_groups);
+	// the two waves of a u8 pair do unequal work (forward: Y + Cg against Co + alpha) and wave w of a
+	// workgroup runs on SIMD w % 4: swap the roles in every other workgroup (by bit parity, which does not
+	// correlate with any round-robin placement) so that every SIMD gets both kinds
+	if (P.plane_groups == 2)
+		id.pg ^= (uint32_t)(__builtin_popcount(blk) & 1);
 	u /= P.plane_groups;
 	id.strip = (uint32_t)(u % G.strips);
 	u /= G.strips;
@@ -407,6 +412,14 @@ __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const Stream
 __device__ __forceinline__ uint32_t pack2(int lo, int hi)
 {
 	return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+}
+// same for two values known to lie in the int16 range: one v_cvt_pk_i16_i32 (it saturates, which
+// never triggers here) instead of and + shift-or
+__device__ __forceinline__ uint32_t pack2_inrange(int lo, int hi)
+{
+	typedef short short2v __attribute__((ext_vector_type(2)));
+	const short2v v = __builtin_amdgcn_cvt_pk_i16(lo, hi);
+	return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ int lo16(uint32_t w)
 {
@@ -489,6 +502,9 @@ __device__ __forceinline__ float half_trunc(float x)
 
 // Four RGBA pixels -> the two planes of this wave's pair, the colour mode switch hoisted out of the
 // pixel loop (one wave-uniform branch per row instead of three per pixel).  V = int or float.
+// Forward pairs are (plane 0, plane 2) and (plane 1, plane 3): with YCoCg the first wave then owns
+// Y and Cg (which share t = b + Co/2) and the second only Co = r - b and alpha, so nothing is computed
+// twice and neither wave converts a channel it does not use.
 template <typename V>
 __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int color, int pair, bool discard, V v0[4],
                                                    V v1[4])
@@ -509,27 +525,23 @@ __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int col
 	}
 	if (color == C_YCOCG || color == C_YCOCG_Q)
 	{
-		const V ymul = (color == C_YCOCG_Q) ? (V)2 : (V)1;
 		if (pair == 0)  // wave-uniform
 		{
+			const V ymul = (color == C_YCOCG_Q) ? (V)2 : (V)1;
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 			{
 				const V co = r[k] - b[k];
 				const V t = b[k] + half_trunc(co);
 				const V cg = g[k] - t;
-				v0[k] = (t + half_trunc(cg)) * ymul, v1[k] = co;
+				v0[k] = (t + half_trunc(cg)) * ymul, v1[k] = cg;
 			}
 		}
 		else
 		{
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-			{
-				const V co = r[k] - b[k];
-				const V t = b[k] + half_trunc(co);
-				v0[k] = g[k] - t, v1[k] = a[k];
-			}
+				v0[k] = r[k] - b[k], v1[k] = a[k];
 		}
 	}
 	else if (color == C_SUBG)
@@ -537,8 +549,8 @@ __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int col
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 		{
-			v0[k] = pair ? (b[k] - g[k]) : g[k];
-			v1[k] = pair ? a[k] : (r[k] - g[k]);
+			v0[k] = pair ? (r[k] - g[k]) : g[k];
+			v1[k] = pair ? a[k] : (b[k] - g[k]);
 		}
 	}
 	else
@@ -546,8 +558,8 @@ __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int col
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 		{
-			v0[k] = pair ? b[k] : r[k];
-			v1[k] = pair ? a[k] : g[k];
+			v0[k] = pair ? g[k] : r[k];
+			v1[k] = pair ? a[k] : b[k];
 		}
 	}
 }
@@ -651,7 +663,10 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
 	const int chh = (int)P.full_h;
 	const int wrap = P.wrap;
-	const int p_first = (U8 && NPL == 2) ? 2 * (int)id.pg : (int)id.pg;
+	// planes of this wave: pg alone on int16 planes; on the u8 side the pair (pg, pg + 2), see
+	// decode_pixels_pair()
+	const int p_first = (int)id.pg;
+	constexpr int P_STEP = (U8 && NPL == 2) ? 2 : 1;
 	const int c0 = lc.c0;
 
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
@@ -685,7 +700,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 	{
-		const int pl = p_first + p;
+		const int pl = p_first + p * P_STEP;
 		grp_base[p] = tile_stream + P.grp_off[pl] + 1 + c0;
 		if (P.ll_out_stream)
 			ll_base[p] = tile_stream + P.lp_off[pl] + c0;
@@ -699,7 +714,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	if (id.strip == 0 && id.seg == 0 && lane == 0)
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
-			tile_stream[P.grp_off[p_first + p]] = (int16_t)((p_first + p == 0) ? P.q_luma : P.q_chroma);
+			tile_stream[P.grp_off[p_first + p * P_STEP]] = (int16_t)((p_first + p * P_STEP == 0) ? P.q_luma : P.q_chroma);
 
 	const float gf_luma = (float)P.g_luma, gf_chroma = (float)P.g_chroma;
 
@@ -719,7 +734,9 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 #pragma unroll
 		for (int par = 0; par < 2; par++)
 		{
-			const int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
+			int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
+			if (P.dbg & 16)  // timing experiment: every row loads row 0 / 1
+				y = par;
 #ifdef AKO_EXPERIMENT_NO_LOADS  // timing experiment only: wrong results
 			if (y == 12345678)
 #endif
@@ -788,12 +805,12 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					vstep_forward<KIND, NARROW, VEDGE, K, V>(st[p][k], e[k], o[k], v, wrap, Tr, lp[k], hp[k]);
 
 				// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
-				const float gf = (p_first + p == 0) ? gf_luma : gf_chroma;
-				const float rq = (p_first + p == 0) ? P.rq_luma : P.rq_chroma;
-				w_ll[p] = pack2(to_int(lp[0]), to_int(lp[1]));
-				w_c[p] = pack2(quantize_f(hp[0], gf, rq), quantize_f(hp[1], gf, rq));
-				w_b[p] = pack2(quantize_f(lp[2], gf, rq), quantize_f(lp[3], gf, rq));
-				w_d[p] = pack2(quantize_f(hp[2], gf, rq), quantize_f(hp[3], gf, rq));
+				const float gf = (p_first + p * P_STEP == 0) ? gf_luma : gf_chroma;
+				const float rq = (p_first + p * P_STEP == 0) ? P.rq_luma : P.rq_chroma;
+				w_ll[p] = pack2_inrange(to_int(lp[0]), to_int(lp[1]));
+				w_c[p] = pack2_inrange(quantize_f(hp[0], gf, rq), quantize_f(hp[1], gf, rq));
+				w_b[p] = pack2_inrange(quantize_f(lp[2], gf, rq), quantize_f(lp[3], gf, rq));
+				w_d[p] = pack2_inrange(quantize_f(hp[2], gf, rq), quantize_f(hp[3], gf, rq));
 			}
 			if ((r >= r_lo) && (r < r_hi))  // wave-uniform
 			{
@@ -802,12 +819,11 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 #pragma unroll
 					for (int p = 0; p < NPL; p++)
 					{
-						int16_t* grp = grp_base[p] + (uint64_t)r * Tc;
-						if (P.dbg & 1)  // timing experiment: force 4-byte aligned stream stores (wrong output)
-							grp = reinterpret_cast<int16_t*>(reinterpret_cast<uintptr_t>(grp) & ~(uintptr_t)3);
+						const uint64_t rr = (P.dbg & 8) ? 0 : (uint64_t)r;  // timing experiment: every row stores to row 0
+						int16_t* grp = grp_base[p] + rr * Tc;
 						if (P.dbg & 2)  // timing experiment: skip the stream stores
 							continue;
-						*reinterpret_cast<uint32_t*>(ll_base[p] + (uint64_t)r * ll_pitch) = w_ll[p];
+						*reinterpret_cast<uint32_t*>(ll_base[p] + rr * ll_pitch) = w_ll[p];
 						*reinterpret_cast<uint32_t*>(grp) = w_c[p];
 						*reinterpret_cast<uint32_t*>(grp + nsub) = w_b[p];
 						*reinterpret_cast<uint32_t*>(grp + 2 * nsub) = w_d[p];
@@ -1141,7 +1157,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 }
 
 template <int KIND, int NPL, bool U8, bool OPT>
-__global__ __launch_bounds__(THREADS) void k_inverse_stream(const LevelParams P, const StreamGeom G)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_inverse_stream(const LevelParams P, const StreamGeom G)
 {
 	__shared__ uint4 xbuf[2][2][2][64];  // U8 only: [slot parity][destination wave of the pair][plane][lane]
 	if (!OPT && P.ovf_flag != nullptr)

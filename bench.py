@@ -309,7 +309,8 @@ def main():
                                "sum_kernel_ms": round(kern_ms, 4)},
             },
             "kernels": [{"name": k[0], "level": k[1], "ms": round(a["ms"] / a["n"], 4),
-                         "GBps": round(a["bytes"] / (a["ms"] / a["n"] * 1e-3) / 1e9, 1)}
+                         "GBps": round(a["bytes"] / (a["ms"] / a["n"] * 1e-3) / 1e9, 1),
+                         "isolated_ms": round(sum(iso[k]) / len(iso[k]), 4) if k in iso else None}
                         for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])],
         }
         if not args.no_cpu_baseline:

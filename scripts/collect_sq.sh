@@ -4,7 +4,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/sq_${1:-full8192}
 mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --workload ${1:-full8192} --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/p1.json" 2> "$OUT/p1.err" || { tail -5 "$OUT/p1.err"; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --workload ${1:-full8192} --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/p1.json" 2> "$OUT/p1.err" || { tail -5 "$OUT/p1.err"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, os
 from collections import defaultdict

@@ -3,7 +3,7 @@
 import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/ako_plan.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only"] + os.environ.get("AKO_HIPCC_EXTRA", "").split() + ["-o", out,
                 os.path.join(ROOT, "ako_amd/csrc/ako_plan.hip")], check=True, stderr=subprocess.DEVNULL)
 txt = open(out).read()
 filt = sys.argv[1] if len(sys.argv) > 1 else ""
