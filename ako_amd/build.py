@@ -63,5 +63,27 @@ def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
     return OUT
 
 
+TOOLS = os.path.join(os.path.dirname(HERE), "tools")
+TOOL_BIN = os.path.join(TOOLS, "bin")
+
+
+def build_tools(force: bool = False) -> str:
+    """akoenc / akodec (link ako_amd/libako.so) and pngcheck (no GPU code) into tools/bin/."""
+    build()
+    os.makedirs(TOOL_BIN, exist_ok=True)
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    common = [os.path.join(TOOLS, "cli_common.hpp"), os.path.join(inc, "ako.h")]
+    for name, with_lib in (("akoenc", True), ("akodec", True), ("pngcheck", False)):
+        src, exe = os.path.join(TOOLS, name + ".cpp"), os.path.join(TOOL_BIN, name)
+        if force or _stale(exe, [src] + common + ([OUT] if with_lib else [])):
+            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", f"-I{inc}", f"-I{TOOLS}", src, "-o", exe]
+            if with_lib:
+                cmd += [f"-L{HERE}", "-lako", "-Wl,-rpath,$ORIGIN/../../ako_amd", "-Wl,-rpath-link,/opt/rocm/lib"]
+            _run(cmd + ["-lz"])
+    return TOOL_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--tools" in sys.argv:
+        build_tools(force="--force" in sys.argv)
