@@ -136,6 +136,14 @@ def lib() -> C.CDLL:
     L.akoHipPlanKernelRecords.restype = sz
     L.akoHipPlanKernelRecords.argtypes = [vp, C.c_int, C.POINTER(KernelRecord), sz]
     # host-side helpers (exported for the host-logic tests)
+    L.akoHipEncodeUpload.restype = C.c_int
+    L.akoHipEncodeUpload.argtypes = [vp, vp]
+    L.akoHipKagariEncode.restype = C.c_int
+    L.akoHipKagariEncode.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.akoHipKagariFetch.restype = C.c_int
+    L.akoHipKagariFetch.argtypes = [vp, vp]
+    L.akoHipKagariBody.restype = vp
+    L.akoHipKagariBody.argtypes = [vp]
     L.akoHostQuantStep.restype = C.c_int16
     L.akoHostQuantStep.argtypes = [C.c_int, C.c_int, sz, sz, sz, sz]
     L.akoHostGateStep.restype = C.c_int16
@@ -324,6 +332,18 @@ class Plan:
         q, g = C.c_int(), C.c_int()
         self._check(lib().akoHipPlanQuant(self._p, tile, level, channel, C.byref(q), C.byref(g)), "akoHipPlanQuant")
         return q.value, g.value
+
+    def kagari_encode(self, streams=None, image: int = 0, fetch: bool = True):
+        """akoHipKagariEncode (+ akoHipKagariFetch): the blob body (uint32 size + payload per tile) of one
+        image's coefficient streams, entropy-coded on the GPU.  Raises AkoError when a tile does not shrink."""
+        n, bad = C.c_size_t(0), C.c_size_t(0)
+        ptr = C.c_void_p(streams.data_ptr()) if streams is not None else None
+        self._check(lib().akoHipKagariEncode(self._p, ptr, image, C.byref(n), C.byref(bad)), "akoHipKagariEncode")
+        if not fetch:
+            return n.value
+        out = np.empty(n.value, dtype=np.uint8)
+        self._check(lib().akoHipKagariFetch(self._p, out.ctypes.data_as(C.c_void_p)), "akoHipKagariFetch")
+        return out
 
     def set_profiling(self, on: bool):
         lib().akoHipPlanSetProfiling(self._p, 1 if on else 0)

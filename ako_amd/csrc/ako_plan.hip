@@ -8,6 +8,7 @@
 #include "ako_kernels.hip.h"
 #include "ako_stream.hip.h"
 #include "ako_tail.hip.h"
+#include "ako_kagari.hip.h"
 
 #include "../../include/ako_hip.h"
 
@@ -78,6 +79,32 @@ struct EventPair
 	hipEvent_t a, b;
 };
 
+// buffers of the device Kagari encoder (ako_kagari.hip.h), created on first use
+struct KagariState
+{
+	uint32_t n_tiles = 0, n_blocks = 0;
+	KgTile* d_tiles = nullptr;
+	uint64_t* d_tile_stage = nullptr;  // byte offset of every tile's staging area
+	uint32_t* d_block_runs = nullptr;  // runs per block, then (scanned in place) first run of every block
+	uint32_t* d_total_runs = nullptr;
+	uint32_t* d_run_start = nullptr;
+	uint32_t* d_run_bits = nullptr;
+	size_t run_capacity = 0;
+	uint64_t* d_block_bits = nullptr;  // bits per block of runs, then (scanned in place) bit offset
+	size_t block_bits_capacity = 0;
+	uint64_t* d_total_bits = nullptr;
+	uint32_t* d_tile_first_run = nullptr;
+	uint64_t* d_tile_bit_off = nullptr;
+	uint64_t* d_tile_payload = nullptr;
+	uint64_t* d_tile_dst = nullptr;
+	KgResult* d_result = nullptr;
+	uint8_t* d_stage = nullptr;
+	size_t stage_bytes = 0;
+	uint8_t* d_body = nullptr;
+	size_t body_capacity = 0;
+	size_t body_bytes = 0;  // of the last successful call
+};
+
 }  // namespace
 
 struct akoHipPlan
@@ -106,6 +133,7 @@ struct akoHipPlan
 		size_t ev;
 	};
 	std::vector<Pending> pending[2];
+	KagariState* kg = nullptr;
 };
 
 namespace
@@ -925,6 +953,17 @@ void akoHipPlanDestroy(akoHipPlan* pl)
 		(void)hipFree(pl->d_stream);
 	if (pl->d_flags)
 		(void)hipFree(pl->d_flags);
+	if (pl->kg)
+	{
+		KagariState* k = pl->kg;
+		void* bufs[] = {k->d_tiles, k->d_tile_stage, k->d_block_runs, k->d_total_runs, k->d_run_start, k->d_run_bits,
+		                k->d_block_bits, k->d_total_bits, k->d_tile_first_run, k->d_tile_bit_off, k->d_tile_payload,
+		                k->d_tile_dst, k->d_result, k->d_stage, k->d_body};
+		for (void* b : bufs)
+			if (b)
+				(void)hipFree(b);
+		delete k;
+	}
 	for (int d = 0; d < 2; d++)
 		for (EventPair& e : pl->events[d])
 		{
@@ -1086,6 +1125,169 @@ size_t akoHipPlanKernelRecords(akoHipPlan* pl, int decode, struct akoHipKernelRe
 		n++;
 	}
 	return n;
+}
+
+// ---- device Kagari encoder ------------------------------------------------------------------------
+
+static int kagari_state(akoHipPlan* pl)
+{
+	if (pl->kg)
+		return 0;
+	if (pl->flags & AKO_HIP_PLAN_PLANES_I16)
+		return fail(AKO_INVALID_INPUT, "the entropy stage works on coefficient streams, not on PLANES_I16 plans%s%s");
+	if (pl->stream_values == 0 || pl->stream_values > 0xFFFFFFF0ull)
+		return fail(AKO_ERROR, "stream too large for the device entropy stage%s%s");
+	KagariState* k = new KagariState;
+	pl->kg = k;
+	std::vector<KgTile> tiles(pl->tiles.size());
+	std::vector<uint64_t> stage(pl->tiles.size());
+	uint64_t blocks = 0, expect = 0;
+	for (size_t t = 0; t < pl->tiles.size(); t++)
+	{
+		const TileInfo& ti = pl->tiles[t];
+		if (ti.stream_off != expect)  // the run logic relies on tiles being contiguous and in order
+			return fail(AKO_ERROR, "internal: tile streams are not contiguous%s%s");
+		expect += ti.stream_bytes;
+		tiles[t].off = ti.stream_off / 2, tiles[t].n = ti.stream_bytes / 2;
+		tiles[t].first_block = (uint32_t)blocks, tiles[t].pad = 0;
+		blocks += (tiles[t].n + KG_CHUNK - 1) / KG_CHUNK;
+		stage[t] = ((ti.stream_off + 7) & ~(uint64_t)7) + 16 * t;  // 8-byte aligned, 8+ bytes of slack each
+	}
+	k->n_tiles = (uint32_t)tiles.size(), k->n_blocks = (uint32_t)blocks;
+	k->stage_bytes = pl->stream_values * 2 + 16 * tiles.size() + 32;
+	k->body_capacity = pl->stream_values * 2 + 4 * tiles.size();
+#define KG_ALLOC(ptr, bytes)                                                                \
+	if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess)                                   \
+		return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(device entropy stage) failed%s%s")
+	KG_ALLOC(k->d_tiles, tiles.size() * sizeof(KgTile));
+	KG_ALLOC(k->d_tile_stage, tiles.size() * 8);
+	KG_ALLOC(k->d_block_runs, (blocks + 1) * 4);
+	KG_ALLOC(k->d_total_runs, 8);
+	KG_ALLOC(k->d_total_bits, 8);
+	KG_ALLOC(k->d_tile_first_run, tiles.size() * 4);
+	KG_ALLOC(k->d_tile_bit_off, tiles.size() * 8);
+	KG_ALLOC(k->d_tile_payload, tiles.size() * 8);
+	KG_ALLOC(k->d_tile_dst, tiles.size() * 8);
+	KG_ALLOC(k->d_result, sizeof(KgResult));
+	KG_ALLOC(k->d_stage, k->stage_bytes);
+	KG_ALLOC(k->d_body, k->body_capacity);
+	HIP_TRY(hipMemcpy(k->d_tiles, tiles.data(), tiles.size() * sizeof(KgTile), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(k->d_tile_stage, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
+	return 0;
+}
+
+int akoHipEncodeUpload(akoHipPlan* pl, const void* h_images)
+{
+	if (!pl || !h_images)
+		return fail(AKO_INVALID_INPUT, "null argument%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	if (int rc = ensure_staging(pl))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(pl->d_img, h_images, akoHipPlanImageBytes(pl) * pl->batch, hipMemcpyHostToDevice,
+	                       pl->stream));
+	return akoHipEncode(pl, pl->d_img, pl->d_stream);
+}
+
+int akoHipKagariEncode(akoHipPlan* pl, const void* d_streams, size_t image, size_t* body_bytes, size_t* failed_tile)
+{
+	if (!pl || image >= pl->batch)
+		return fail(AKO_INVALID_INPUT, "null plan or image index out of range%s%s");
+	if (d_streams == nullptr)
+		d_streams = pl->d_stream;
+	if (d_streams == nullptr)
+		return fail(AKO_INVALID_INPUT, "no coefficient streams: pass a device pointer or call akoHipEncodeUpload first%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	if (int rc = kagari_state(pl))
+		return rc;
+	KagariState* k = pl->kg;
+	k->body_bytes = 0;
+	hipStream_t st = pl->stream;
+	const int16_t* s = static_cast<const int16_t*>(d_streams) + image * pl->stream_values;
+
+	// 1-2: run starts per block, first run of every block
+	hipLaunchKernelGGL(k_kg_starts<false>, dim3(k->n_blocks), dim3(KG_THREADS), 0, st, s, k->d_tiles, k->n_tiles,
+	                   k->d_block_runs, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+	hipLaunchKernelGGL(k_kg_scan<uint32_t>, dim3(1), dim3(KG_SCAN_THREADS), 0, st, k->d_block_runs, k->d_block_runs,
+	                   (uint64_t)k->n_blocks, k->d_total_runs);
+	uint32_t n_runs = 0;
+	HIP_TRY(hipMemcpyAsync(&n_runs, k->d_total_runs, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const uint32_t run_blocks = (n_runs + KG_THREADS - 1) / KG_THREADS;
+	if (n_runs > k->run_capacity)
+	{
+		if (k->d_run_start)
+			(void)hipFree(k->d_run_start), k->d_run_start = nullptr;
+		if (k->d_run_bits)
+			(void)hipFree(k->d_run_bits), k->d_run_bits = nullptr;
+		k->run_capacity = 0;
+		const size_t want = (size_t)n_runs + n_runs / 4 + 1024;
+		KG_ALLOC(k->d_run_start, want * 4);
+		KG_ALLOC(k->d_run_bits, want * 4);
+		k->run_capacity = want;
+	}
+	if (run_blocks > k->block_bits_capacity)
+	{
+		if (k->d_block_bits)
+			(void)hipFree(k->d_block_bits), k->d_block_bits = nullptr;
+		k->block_bits_capacity = 0;
+		const size_t want = (size_t)run_blocks + run_blocks / 4 + 64;
+		KG_ALLOC(k->d_block_bits, want * 8);
+		k->block_bits_capacity = want;
+	}
+#undef KG_ALLOC
+	// 3-6: runs, their bits, bit offsets, tile layout
+	hipLaunchKernelGGL(k_kg_starts<true>, dim3(k->n_blocks), dim3(KG_THREADS), 0, st, s, k->d_tiles, k->n_tiles,
+	                   (uint32_t*)nullptr, (const uint32_t*)k->d_block_runs, k->d_run_start);
+	hipLaunchKernelGGL(k_kg_bits, dim3(run_blocks), dim3(KG_THREADS), 0, st, s, (const uint32_t*)k->d_run_start, n_runs,
+	                   (uint64_t)pl->stream_values, k->d_run_bits, k->d_block_bits);
+	hipLaunchKernelGGL(k_kg_scan<uint64_t>, dim3(1), dim3(KG_SCAN_THREADS), 0, st, k->d_block_bits, k->d_block_bits,
+	                   (uint64_t)run_blocks, k->d_total_bits);
+	hipLaunchKernelGGL(k_kg_tiles, dim3(k->n_tiles), dim3(64), 0, st, (const KgTile*)k->d_tiles, k->n_tiles,
+	                   (const uint32_t*)k->d_block_runs, (const uint32_t*)k->d_run_bits, (const uint64_t*)k->d_block_bits,
+	                   k->d_tile_first_run, k->d_tile_bit_off);
+	hipLaunchKernelGGL(k_kg_layout, dim3(1), dim3(KG_SCAN_THREADS), 0, st, (const KgTile*)k->d_tiles, k->n_tiles,
+	                   (const uint64_t*)k->d_tile_bit_off, (const uint64_t*)k->d_total_bits, k->d_tile_payload, k->d_tile_dst,
+	                   k->d_result);
+	// 7: the bits (into zeroed staging areas)
+	HIP_TRY(hipMemsetAsync(k->d_stage, 0, k->stage_bytes, st));
+	hipLaunchKernelGGL(k_kg_write, dim3(run_blocks), dim3(KG_THREADS), 0, st, s, (const uint32_t*)k->d_run_start,
+	                   (const uint32_t*)k->d_run_bits, n_runs, (uint64_t)pl->stream_values, (const uint64_t*)k->d_block_bits,
+	                   (const uint32_t*)k->d_tile_first_run, (const uint64_t*)k->d_tile_bit_off,
+	                   (const uint64_t*)k->d_tile_stage, k->n_tiles, (const KgResult*)k->d_result, k->d_stage);
+	KgResult res;
+	HIP_TRY(hipMemcpyAsync(&res, k->d_result, sizeof res, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (res.failed_tile != 0xFFFFFFFFu)
+	{
+		if (failed_tile)
+			*failed_tile = res.failed_tile;
+		return fail(AKO_ERROR, "a tile did not shrink under Kagari (library/encode.c:159-164)%s%s");
+	}
+	// 8: blob body
+	const uint32_t gather_blocks = (uint32_t)((res.body_bytes + KG_GATHER_BYTES - 1) / KG_GATHER_BYTES);
+	hipLaunchKernelGGL(k_kg_gather, dim3(gather_blocks), dim3(KG_THREADS), 0, st, (const uint8_t*)k->d_stage,
+	                   (const uint64_t*)k->d_tile_stage, (const uint64_t*)k->d_tile_payload, (const uint64_t*)k->d_tile_dst,
+	                   k->n_tiles, (uint64_t)res.body_bytes, k->d_body);
+	HIP_TRY(hipGetLastError());
+	k->body_bytes = res.body_bytes;
+	if (body_bytes)
+		*body_bytes = res.body_bytes;
+	return 0;
+}
+
+int akoHipKagariFetch(akoHipPlan* pl, void* h_body)
+{
+	if (!pl || !pl->kg || !h_body || pl->kg->body_bytes == 0)
+		return fail(AKO_INVALID_INPUT, "no entropy-coded body to fetch%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	HIP_TRY(hipMemcpyAsync(h_body, pl->kg->d_body, pl->kg->body_bytes, hipMemcpyDeviceToHost, pl->stream));
+	HIP_TRY(hipStreamSynchronize(pl->stream));
+	return 0;
+}
+
+const void* akoHipKagariBody(const akoHipPlan* pl)
+{
+	return (pl && pl->kg && pl->kg->body_bytes) ? pl->kg->d_body : nullptr;
 }
 
 }  // extern "C"

@@ -85,6 +85,66 @@ AKO_API size_t akoEncodeExt(const struct akoCallbacks* c, const struct akoSettin
 
 	const size_t tiles = akoHipPlanTiles(plan);
 	const size_t stream_bytes = akoHipPlanStreamBytes(plan);
+
+	/* Entropy stage on the GPU (default): the coefficient streams stay on the device and only the
+	 * compressed body comes back.  AKO_HIP_KAGARI=host keeps the streams-to-host + host Kagari route. */
+	const char* kg_env = getenv("AKO_HIP_KAGARI");
+	const int device_kagari = (st.compression != AKO_COMPRESSION_NONE) && !(kg_env != NULL && strcmp(kg_env, "host") == 0);
+
+	if (device_kagari)
+	{
+		for (size_t t = 0; t < tiles; t++)
+		{
+			fire(&cb, t, tiles, AKO_EVENT_FORMAT_START);
+			fire(&cb, t, tiles, AKO_EVENT_FORMAT_END);
+			if (st.wavelet != AKO_WAVELET_NONE)
+				fire(&cb, t, tiles, AKO_EVENT_WAVELET_START);
+			if (t == 0)
+			{
+				int rc = akoHipEncodeUpload(plan, in);
+				if (rc == 0)
+					rc = akoHipSynchronize(plan);
+				if (rc != 0)
+				{
+					status = (enum akoStatus)rc;
+					complain("akoEncodeExt");
+					goto failure;
+				}
+			}
+			if (st.wavelet != AKO_WAVELET_NONE)
+				fire(&cb, t, tiles, AKO_EVENT_WAVELET_END);
+
+			fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_START);
+			if (t == 0)
+			{
+				size_t body = 0, bad_tile = 0;
+				const int rc = akoHipKagariEncode(plan, NULL, 0, &body, &bad_tile);
+				if (rc != 0)
+				{
+					status = (enum akoStatus)rc; /* AKO_ERROR when a tile did not shrink: encode.c:159-164 */
+					if (rc != AKO_ERROR)
+						complain("akoEncodeExt");
+					goto failure;
+				}
+				uint8_t* grown = cb.realloc(blob, blob_size + body);
+				if (grown == NULL)
+				{
+					status = AKO_NO_ENOUGH_MEMORY;
+					goto failure;
+				}
+				blob = grown;
+				if ((status = (enum akoStatus)akoHipKagariFetch(plan, blob + blob_size)) != AKO_OK)
+				{
+					complain("akoEncodeExt");
+					goto failure;
+				}
+				blob_size += body;
+			}
+			fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_END);
+		}
+		goto done;
+	}
+
 	if ((streams = cb.malloc(stream_bytes)) == NULL)
 	{
 		status = AKO_NO_ENOUGH_MEMORY;
@@ -173,8 +233,10 @@ AKO_API size_t akoEncodeExt(const struct akoCallbacks* c, const struct akoSettin
 		fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_END);
 	}
 
+done:
 	akoHipPlanDestroy(plan);
-	cb.free(streams);
+	if (streams != NULL)
+		cb.free(streams);
 	if (packed != NULL)
 		cb.free(packed);
 
@@ -314,7 +376,8 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	}
 
 	akoHipPlanDestroy(plan);
-	cb.free(streams);
+	if (streams != NULL)
+		cb.free(streams);
 
 	if (out_s != NULL)
 		*out_s = st;

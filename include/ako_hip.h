@@ -106,6 +106,26 @@ struct akoHipKernelRecord
 int akoHipPlanSetProfiling(akoHipPlan*, int enabled);
 size_t akoHipPlanKernelRecords(akoHipPlan*, int decode, struct akoHipKernelRecord* out, size_t capacity);
 
+/* ---- device entropy stage: Kagari ENCODER on the GPU --------------------------------
+ * Replaces the per-tile akoCompress() -> akoKagariEncode() calls of the encoder (library/encode.c:151-175,
+ * library/compression.c:36-55, library/kagari.c:228-366) for all tiles of one image at once: the
+ * coefficient streams never leave the GPU, only the compressed blob body does.
+ *
+ * akoHipEncodeUpload   copy a batch of host images to the device and transform them into the plan's own
+ *                      stream buffer (akoHipEncodeHost without the copy back)
+ * akoHipKagariEncode   entropy-code every tile stream of image `image` of d_streams (NULL = the plan's own
+ *                      buffer).  On success *body_bytes is the size of the blob body: per tile, in tile
+ *                      order, a little-endian uint32 payload size followed by the payload -- exactly what
+ *                      follows the 16 byte head in a blob with compression KAGARI.  When a tile does not
+ *                      shrink the reference encoder gives up (library/encode.c:159-164): returns AKO_ERROR
+ *                      with *failed_tile set.  The body stays in plan-owned device memory
+ * akoHipKagariFetch    copy that body to host memory (synchronous)
+ * akoHipKagariBody     its device address, for device-resident callers */
+int akoHipEncodeUpload(akoHipPlan*, const void* h_images);
+int akoHipKagariEncode(akoHipPlan*, const void* d_streams, size_t image, size_t* body_bytes, size_t* failed_tile);
+int akoHipKagariFetch(akoHipPlan*, void* h_body);
+const void* akoHipKagariBody(const akoHipPlan*);
+
 #ifdef __cplusplus
 }
 #endif

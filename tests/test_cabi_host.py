@@ -202,3 +202,34 @@ def test_no_gpu_fails_loudly_not_silently():
     with pytest.raises(api.AkoError) as e:
         api.decode(np.zeros(64, np.uint8))
     assert e.value.status == 11
+
+
+def test_kagari_capacity_rule_closed_form():
+    """The device encoder decides 'did the tile shrink' from the payload size alone: the host encoder
+    (= library/kagari.c:64-112, pinned above) must succeed exactly when capacity >= payload + 1."""
+    import ctypes as C
+
+    from ako_amd import api
+
+    L = api.lib()
+    V = C.c_void_p
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        n = int(rng.integers(1, 400))
+        kind = trial % 4
+        if kind == 0:
+            v = rng.integers(-3, 4, n)
+        elif kind == 1:
+            v = rng.integers(-32768, 32768, n)
+        elif kind == 2:
+            v = np.repeat(rng.integers(-100, 100, (n + 7) // 8), 8)[:n]
+        else:
+            v = np.where(rng.random(n) < 0.8, 0, rng.integers(-5000, 5000, n))
+        v = np.ascontiguousarray(v.astype(np.int16))
+        big = np.zeros(8 * n + 64, dtype=np.uint8)
+        size = L.akoHostKagariEncode(n * 2, big.size, v.ctypes.data_as(V), big.ctypes.data_as(V))
+        assert size > 0
+        for cap in range(max(size - 12, 1), size + 12):
+            out = np.zeros(cap + 8, dtype=np.uint8)
+            got = L.akoHostKagariEncode(n * 2, cap, v.ctypes.data_as(V), out.ctypes.data_as(V))
+            assert (got == size) if cap >= size + 1 else (got == 0), (trial, n, size, cap, got)
