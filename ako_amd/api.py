@@ -66,6 +66,15 @@ class Callbacks(C.Structure):
                 ("events_data", C.c_void_p)]
 
 
+class KagariRun(C.Structure):
+    _fields_ = [("out_start", C.c_uint32), ("count", C.c_uint32), ("after", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class KagariTokens(C.Structure):
+    _fields_ = [("literals", C.POINTER(C.c_int16)), ("n_literals", C.c_size_t), ("cap_literals", C.c_size_t),
+                ("runs", C.POINTER(KagariRun)), ("n_runs", C.c_size_t), ("cap_runs", C.c_size_t)]
+
+
 class KernelRecord(C.Structure):
     """struct akoHipKernelRecord (include/ako_hip.h)."""
 
@@ -144,6 +153,14 @@ def lib() -> C.CDLL:
     L.akoHipKagariFetch.argtypes = [vp, vp]
     L.akoHipKagariBody.restype = vp
     L.akoHipKagariBody.argtypes = [vp]
+    L.akoHipKagariExpand.restype = C.c_int
+    L.akoHipKagariExpand.argtypes = [vp, C.POINTER(C.c_int16), sz, C.POINTER(KagariRun), sz, vp, sz]
+    L.akoHipDecodeDownload.restype = C.c_int
+    L.akoHipDecodeDownload.argtypes = [vp, vp]
+    L.akoHostKagariTokenize.restype = sz
+    L.akoHostKagariTokenize.argtypes = [sz, sz, vp, C.c_uint64, C.POINTER(KagariTokens)]
+    L.akoHostKagariTokensFree.restype = None
+    L.akoHostKagariTokensFree.argtypes = [C.POINTER(KagariTokens)]
     L.akoHostQuantStep.restype = C.c_int16
     L.akoHostQuantStep.argtypes = [C.c_int, C.c_int, sz, sz, sz, sz]
     L.akoHostGateStep.restype = C.c_int16
@@ -344,6 +361,33 @@ class Plan:
         out = np.empty(n.value, dtype=np.uint8)
         self._check(lib().akoHipKagariFetch(self._p, out.ctypes.data_as(C.c_void_p)), "akoHipKagariFetch")
         return out
+
+    def kagari_decode_body(self, body: np.ndarray, streams=None, image: int = 0):
+        """The decoder's entropy stage, device route: parse a blob body ([uint32 size][payload] per tile) on the
+        host (akoHostKagariTokenize), expand the runs on the GPU (akoHipKagariExpand) into `streams`."""
+        body = np.ascontiguousarray(body, dtype=np.uint8)
+        if streams is None:
+            streams = self.new_streams()
+        tok = KagariTokens()
+        at = 0
+        try:
+            for t in range(self.tiles):
+                ti = self.tile_info(t)
+                if body.size - at < 4:
+                    raise AkoError(15, "kagari_decode_body", "truncated body")
+                block = int(body[at:at + 4].view("<u4")[0])
+                if body.size - at - 4 < block:
+                    raise AkoError(15, "kagari_decode_body", "truncated body")
+                used = lib().akoHostKagariTokenize(ti["stream_bytes"] // 2, block, C.c_void_p(body.ctypes.data + at + 4),
+                                                   ti["stream_offset"] // 2, C.byref(tok))
+                if used == 0 or used != block:
+                    raise AkoError(15, "kagari_decode_body", f"tile {t}: broken bit-stream")
+                at += block + 4
+            self._check(lib().akoHipKagariExpand(self._p, tok.literals, tok.n_literals, tok.runs, tok.n_runs,
+                                                 C.c_void_p(streams.data_ptr()), image), "akoHipKagariExpand")
+        finally:
+            lib().akoHostKagariTokensFree(C.byref(tok))
+        return streams
 
     def set_profiling(self, on: bool):
         lib().akoHipPlanSetProfiling(self._p, 1 if on else 0)

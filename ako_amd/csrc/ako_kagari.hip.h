@@ -158,8 +158,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_kg_starts(const int16_t* __restr
 // ---- 2 / 5: exclusive scan by ONE workgroup (n up to a few million) --------------------------------
 
 template <typename T>
-__global__ __launch_bounds__(KG_SCAN_THREADS) void k_kg_scan(const T* __restrict__ in, T* __restrict__ out, uint64_t n,
-                                                             T* __restrict__ total)
+__global__ __launch_bounds__(KG_SCAN_THREADS) void k_kg_scan(const T* in, T* out, uint64_t n, T* total)  // in == out allowed
 {
 	__shared__ T sums[KG_SCAN_THREADS];
 	const uint64_t per = (n + KG_SCAN_THREADS - 1) / KG_SCAN_THREADS;
@@ -384,6 +383,60 @@ __global__ __launch_bounds__(KG_THREADS) void k_kg_gather(const uint8_t* __restr
 		else
 			v = stage[tile_stage[t] + rel - 4];
 		body[at] = v;
+	}
+}
+
+// ---- decoder side: expand (literals, runs) into the coefficient stream -----------------------------
+
+struct KgRun  // = struct akoHipKagariRun
+{
+	uint32_t out_start, count, after, pad;
+};
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_expand(const int16_t* __restrict__ literals, const KgRun* __restrict__ runs,
+                                                          uint32_t n_runs, uint64_t n_out, int16_t* __restrict__ out)
+{
+	__shared__ uint32_t range[2];
+	const uint64_t base = (uint64_t)blockIdx.x * KG_CHUNK;
+	if (threadIdx.x < 2)  // runs that can matter to this block's outputs: [range[0], range[1])
+	{
+		const uint64_t probe = threadIdx.x ? ((base + KG_CHUNK - 1 < n_out) ? base + KG_CHUNK - 1 : n_out - 1) : base;
+		uint32_t lo = 0, hi = n_runs;  // number of runs with out_start <= probe
+		while (lo < hi)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+			if ((uint64_t)runs[mid].out_start <= probe)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		range[threadIdx.x] = threadIdx.x ? lo : (lo ? lo - 1 : 0);
+	}
+	__syncthreads();
+	const uint32_t r_lo = range[0], r_hi = range[1];
+#pragma unroll
+	for (int j = 0; j < KG_PER_THREAD; j++)
+	{
+		const uint64_t i = base + kg_slot(j);
+		if (i >= n_out)
+			break;
+		uint32_t lo = r_lo, hi = r_hi;  // number of runs with out_start <= i, searched inside the block's range
+		while (lo < hi)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+			if ((uint64_t)runs[mid].out_start <= i)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		uint64_t lit = i;
+		if (lo != 0)
+		{
+			const KgRun r = runs[lo - 1];
+			const uint64_t run_end = (uint64_t)r.out_start + r.count;
+			lit = (i < run_end) ? (uint64_t)r.after - 1 : i - (run_end - r.after);
+		}
+		out[i] = literals[lit];
 	}
 }
 

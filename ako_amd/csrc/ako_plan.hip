@@ -103,6 +103,12 @@ struct KagariState
 	uint8_t* d_body = nullptr;
 	size_t body_capacity = 0;
 	size_t body_bytes = 0;  // of the last successful call
+	bool encoder_ready = false;
+	// decoder side
+	int16_t* d_literals = nullptr;
+	size_t literal_capacity = 0;
+	KgRun* d_runs = nullptr;
+	size_t run_record_capacity = 0;
 };
 
 }  // namespace
@@ -958,7 +964,7 @@ void akoHipPlanDestroy(akoHipPlan* pl)
 		KagariState* k = pl->kg;
 		void* bufs[] = {k->d_tiles, k->d_tile_stage, k->d_block_runs, k->d_total_runs, k->d_run_start, k->d_run_bits,
 		                k->d_block_bits, k->d_total_bits, k->d_tile_first_run, k->d_tile_bit_off, k->d_tile_payload,
-		                k->d_tile_dst, k->d_result, k->d_stage, k->d_body};
+		                k->d_tile_dst, k->d_result, k->d_stage, k->d_body, k->d_literals, k->d_runs};
 		for (void* b : bufs)
 			if (b)
 				(void)hipFree(b);
@@ -1131,14 +1137,17 @@ size_t akoHipPlanKernelRecords(akoHipPlan* pl, int decode, struct akoHipKernelRe
 
 static int kagari_state(akoHipPlan* pl)
 {
-	if (pl->kg)
+	if (pl->kg && pl->kg->encoder_ready)
 		return 0;
 	if (pl->flags & AKO_HIP_PLAN_PLANES_I16)
 		return fail(AKO_INVALID_INPUT, "the entropy stage works on coefficient streams, not on PLANES_I16 plans%s%s");
 	if (pl->stream_values == 0 || pl->stream_values > 0xFFFFFFF0ull)
 		return fail(AKO_ERROR, "stream too large for the device entropy stage%s%s");
-	KagariState* k = new KagariState;
-	pl->kg = k;
+	if (pl->kg && pl->kg->d_tiles)
+		return fail(AKO_NO_ENOUGH_MEMORY, "the device entropy stage could not be set up earlier%s%s");
+	if (!pl->kg)
+		pl->kg = new KagariState;
+	KagariState* k = pl->kg;
 	std::vector<KgTile> tiles(pl->tiles.size());
 	std::vector<uint64_t> stage(pl->tiles.size());
 	uint64_t blocks = 0, expect = 0;
@@ -1173,6 +1182,7 @@ static int kagari_state(akoHipPlan* pl)
 	KG_ALLOC(k->d_body, k->body_capacity);
 	HIP_TRY(hipMemcpy(k->d_tiles, tiles.data(), tiles.size() * sizeof(KgTile), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(k->d_tile_stage, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
+	k->encoder_ready = true;
 	return 0;
 }
 
@@ -1288,6 +1298,88 @@ int akoHipKagariFetch(akoHipPlan* pl, void* h_body)
 const void* akoHipKagariBody(const akoHipPlan* pl)
 {
 	return (pl && pl->kg && pl->kg->body_bytes) ? pl->kg->d_body : nullptr;
+}
+
+int akoHipKagariExpand(akoHipPlan* pl, const int16_t* h_literals, size_t n_literals, const struct akoHipKagariRun* h_runs,
+                       size_t n_runs, void* d_streams, size_t image)
+{
+	static_assert(sizeof(KgRun) == sizeof(struct akoHipKagariRun), "record layout");
+	if (!pl || !h_literals || n_literals == 0 || (n_runs != 0 && !h_runs) || image >= pl->batch)
+		return fail(AKO_INVALID_INPUT, "bad argument%s%s");
+	if (pl->flags & AKO_HIP_PLAN_PLANES_I16)
+		return fail(AKO_INVALID_INPUT, "the entropy stage works on coefficient streams, not on PLANES_I16 plans%s%s");
+	if (pl->stream_values > 0xFFFFFFF0ull || n_runs > 0xFFFFFFF0ull)
+		return fail(AKO_ERROR, "stream too large for the device entropy stage%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	if (d_streams == nullptr)
+	{
+		if (int rc = ensure_staging(pl))
+			return rc;
+		d_streams = pl->d_stream;
+	}
+	// the records must describe exactly this image's stream: literals + repeats == values, runs in order
+	// and inside the stream (a forged record must not make the kernel read or write out of range)
+	{
+		uint64_t repeats = 0, prev_end = 0;
+		for (size_t k = 0; k < n_runs; k++)
+		{
+			const struct akoHipKagariRun& r = h_runs[k];
+			if (r.count == 0 || r.after == 0 || r.after > n_literals || r.out_start < prev_end ||
+			    (uint64_t)r.out_start + r.count > pl->stream_values || (uint64_t)r.out_start != (uint64_t)r.after + repeats)
+				return fail(AKO_BROKEN_INPUT, "inconsistent run records%s%s");
+			repeats += r.count;
+			prev_end = (uint64_t)r.out_start + r.count;
+		}
+		if (n_literals + repeats != pl->stream_values)
+			return fail(AKO_BROKEN_INPUT, "run records do not add up to the stream length%s%s");
+	}
+	if (!pl->kg)
+		pl->kg = new KagariState;  // decoder side needs none of the encoder's buffers
+	KagariState* k = pl->kg;
+	if (n_literals > k->literal_capacity)
+	{
+		if (k->d_literals)
+			(void)hipFree(k->d_literals), k->d_literals = nullptr;
+		k->literal_capacity = 0;
+		if (hipMalloc((void**)&k->d_literals, (n_literals + n_literals / 4 + 1024) * 2) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(device entropy stage) failed%s%s");
+		k->literal_capacity = n_literals + n_literals / 4 + 1024;
+	}
+	if (n_runs > k->run_record_capacity)
+	{
+		if (k->d_runs)
+			(void)hipFree(k->d_runs), k->d_runs = nullptr;
+		k->run_record_capacity = 0;
+		if (hipMalloc((void**)&k->d_runs, (n_runs + n_runs / 4 + 1024) * sizeof(KgRun)) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(device entropy stage) failed%s%s");
+		k->run_record_capacity = n_runs + n_runs / 4 + 1024;
+	}
+	hipStream_t st = pl->stream;
+	HIP_TRY(hipMemcpyAsync(k->d_literals, h_literals, n_literals * 2, hipMemcpyHostToDevice, st));
+	if (n_runs)
+		HIP_TRY(hipMemcpyAsync(k->d_runs, h_runs, n_runs * sizeof(KgRun), hipMemcpyHostToDevice, st));
+	int16_t* out = static_cast<int16_t*>(d_streams) + image * pl->stream_values;
+	const uint32_t blocks = (uint32_t)((pl->stream_values + KG_CHUNK - 1) / KG_CHUNK);
+	hipLaunchKernelGGL(k_kg_expand, dim3(blocks), dim3(KG_THREADS), 0, st, (const int16_t*)k->d_literals,
+	                   (const KgRun*)k->d_runs, (uint32_t)n_runs, (uint64_t)pl->stream_values, out);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));  // the host arrays may be released by the caller
+	return 0;
+}
+
+int akoHipDecodeDownload(akoHipPlan* pl, void* h_images)
+{
+	if (!pl || !h_images)
+		return fail(AKO_INVALID_INPUT, "null argument%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	if (int rc = ensure_staging(pl))
+		return rc;
+	if (int rc = akoHipDecode(pl, pl->d_stream, pl->d_img))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(h_images, pl->d_img, akoHipPlanImageBytes(pl) * pl->batch, hipMemcpyDeviceToHost,
+	                       pl->stream));
+	HIP_TRY(hipStreamSynchronize(pl->stream));
+	return 0;
 }
 
 }  // extern "C"

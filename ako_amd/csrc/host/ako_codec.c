@@ -276,6 +276,8 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	uint8_t* image = NULL;
 	uint8_t* streams = NULL;
 	akoHipPlan* plan = NULL;
+	struct akoKagariTokens tokens;
+	memset(&tokens, 0, sizeof tokens);
 
 	const struct akoCallbacks cb = (c != NULL) ? *c : akoDefaultCallbacks();
 	if (cb.malloc == NULL || cb.realloc == NULL || cb.free == NULL)
@@ -305,6 +307,80 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 
 	const size_t tiles = akoHipPlanTiles(plan);
 	const size_t stream_bytes = akoHipPlanStreamBytes(plan);
+	const uint8_t* cursor = (const uint8_t*)input + sizeof(struct akoHead);
+	const uint8_t* const end = (const uint8_t*)input + input_size;
+
+	/* Entropy stage, device route (default): parse the Kagari bit-streams on the host, expand the runs on the
+	 * GPU -- the coefficient streams never exist in host memory.  AKO_HIP_KAGARI=host keeps the old route. */
+	const char* kg_env = getenv("AKO_HIP_KAGARI");
+	if (st.compression != AKO_COMPRESSION_NONE && !(kg_env != NULL && strcmp(kg_env, "host") == 0) &&
+	    stream_bytes / 2 <= 0xFFFFFFF0ull)
+	{
+		if ((image = cb.malloc(image_w * image_h * channels)) == NULL)
+		{
+			status = AKO_NO_ENOUGH_MEMORY;
+			goto failure;
+		}
+		memset(&tokens, 0, sizeof tokens);
+		for (size_t t = 0; t < tiles; t++)
+		{
+			size_t off = 0, bytes = 0;
+			akoHipPlanTileInfo(plan, t, NULL, NULL, NULL, NULL, &off, &bytes);
+
+			fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_START);
+			uint32_t block = 0;
+			if ((size_t)(end - cursor) < 4)
+			{
+				status = AKO_BROKEN_INPUT;
+				goto failure;
+			}
+			memcpy(&block, cursor, 4);
+			if ((size_t)(end - cursor) - 4 < block)
+			{
+				status = AKO_BROKEN_INPUT;
+				goto failure;
+			}
+			const size_t used = akoHostKagariTokenize(bytes / 2, block, cursor + 4, off / 2, &tokens);
+			if (used == 0 || used != block) /* compression.c:69-70 */
+			{
+				status = AKO_BROKEN_INPUT;
+				goto failure;
+			}
+			cursor += (size_t)block + 4;
+			if (t + 1 == tiles)
+			{
+				const int rc = akoHipKagariExpand(plan, tokens.literals, tokens.n_literals,
+				                                  (const struct akoHipKagariRun*)tokens.runs, tokens.n_runs, NULL, 0);
+				if (rc != 0)
+				{
+					status = (enum akoStatus)rc;
+					complain("akoDecodeExt");
+					goto failure;
+				}
+			}
+			fire(&cb, t, tiles, AKO_EVENT_COMPRESSION_END);
+
+			if (st.wavelet != AKO_WAVELET_NONE)
+				fire(&cb, t, tiles, AKO_EVENT_WAVELET_START);
+			if (t + 1 == tiles)
+			{
+				const int rc = akoHipDecodeDownload(plan, image);
+				if (rc != 0)
+				{
+					status = (enum akoStatus)rc;
+					complain("akoDecodeExt");
+					goto failure;
+				}
+			}
+			if (st.wavelet != AKO_WAVELET_NONE)
+				fire(&cb, t, tiles, AKO_EVENT_WAVELET_END);
+			fire(&cb, t, tiles, AKO_EVENT_FORMAT_START);
+			fire(&cb, t, tiles, AKO_EVENT_FORMAT_END);
+		}
+		akoHostKagariTokensFree(&tokens);
+		goto decoded;
+	}
+
 	image = cb.malloc(image_w * image_h * channels);
 	streams = cb.malloc(stream_bytes);
 	if (image == NULL || streams == NULL)
@@ -312,9 +388,6 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 		status = AKO_NO_ENOUGH_MEMORY;
 		goto failure;
 	}
-
-	const uint8_t* cursor = (const uint8_t*)input + sizeof(struct akoHead);
-	const uint8_t* const end = (const uint8_t*)input + input_size;
 
 	for (size_t t = 0; t < tiles; t++)
 	{
@@ -375,6 +448,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 		fire(&cb, t, tiles, AKO_EVENT_FORMAT_END);
 	}
 
+decoded:
 	akoHipPlanDestroy(plan);
 	if (streams != NULL)
 		cb.free(streams);
@@ -392,6 +466,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	return image;
 
 failure:
+	akoHostKagariTokensFree(&tokens);
 	if (plan != NULL)
 		akoHipPlanDestroy(plan);
 	if (cb.free != NULL)

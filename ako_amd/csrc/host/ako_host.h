@@ -29,4 +29,24 @@ AKO_API size_t akoHostKagariEncode(size_t input_bytes, size_t output_capacity, c
 AKO_API size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_bytes, const void* input,
                                    void* output);
 
+/* parse without expanding the runs (device route of the decoder); records are what
+ * akoHipKagariExpand() takes (include/ako_hip.h: struct akoHipKagariRun has the same layout) */
+struct akoKagariRun
+{
+	uint32_t out_start; /* output index (int16 units from the start of the image's stream) of the first repeat */
+	uint32_t count;     /* repeats to write */
+	uint32_t after;     /* literal values decoded before the run; the repeated value is literals[after - 1] */
+	uint32_t pad;
+};
+struct akoKagariTokens
+{
+	int16_t* literals;
+	size_t n_literals, cap_literals;
+	struct akoKagariRun* runs;
+	size_t n_runs, cap_runs;
+};
+AKO_API size_t akoHostKagariTokenize(size_t values_no, size_t input_bytes, const void* input, uint64_t out_base,
+                                     struct akoKagariTokens* tok);
+AKO_API void akoHostKagariTokensFree(struct akoKagariTokens* tok);
+
 #endif

@@ -16,6 +16,7 @@
  */
 #include "ako_host.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #define RUN_LIMIT 65534u /* AKO_ELIAS_MAX - 1 */
@@ -197,4 +198,100 @@ size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_b
 		}
 	}
 	return (s.bitpos + 7) / 8;
+}
+
+
+/* ---- tokenizer: the decoder's parse without the run expansion ------------------------------------
+ * For the device route of the decoder (akoHipKagariExpand): the bit-stream is walked exactly as
+ * akoHostKagariDecode() walks it, but repeated values are not written out -- each run becomes a record
+ * (where it starts in the output, how long, after how many literal values) and the GPU expands them
+ * straight into the coefficient stream.  Host work and the host -> device copy then scale with the
+ * COMPRESSED size.  Output positions are global over the image's stream (tiles are contiguous). */
+
+static int tokens_reserve(struct akoKagariTokens* tok, size_t literals, size_t runs)
+{
+	if (tok->n_literals + literals > tok->cap_literals)
+	{
+		size_t cap = tok->cap_literals ? tok->cap_literals * 2 : 4096;
+		while (cap < tok->n_literals + literals)
+			cap *= 2;
+		int16_t* p = realloc(tok->literals, cap * sizeof(int16_t));
+		if (p == NULL)
+			return 0;
+		tok->literals = p, tok->cap_literals = cap;
+	}
+	if (tok->n_runs + runs > tok->cap_runs)
+	{
+		size_t cap = tok->cap_runs ? tok->cap_runs * 2 : 1024;
+		while (cap < tok->n_runs + runs)
+			cap *= 2;
+		struct akoKagariRun* p = realloc(tok->runs, cap * sizeof(struct akoKagariRun));
+		if (p == NULL)
+			return 0;
+		tok->runs = p, tok->cap_runs = cap;
+	}
+	return 1;
+}
+
+size_t akoHostKagariTokenize(size_t values_no, size_t input_bytes, const void* input, uint64_t out_base,
+                             struct akoKagariTokens* tok)
+{
+	if (input_bytes == 0 || values_no == 0 || out_base + values_no > 0xFFFFFFF0ull)
+		return 0;
+
+	struct bit_source s = {input, input_bytes, 0};
+	size_t done = 0;
+	int16_t prev = 0;
+	unsigned same = 0;
+
+	while (done < values_no)
+	{
+		const uint32_t code = source_get(&s);
+		if (code == 0)
+			return 0;
+		const uint16_t zz = (uint16_t)(code - 1);
+		const int16_t v = (int16_t)((zz >> 1) ^ (uint16_t)(~(zz & 1) + 1));
+		if (tok->n_literals == tok->cap_literals && !tokens_reserve(tok, 1, 0))
+			return 0;
+		tok->literals[tok->n_literals++] = v;
+		done++;
+
+		if (done > 1 && v == prev)
+		{
+			if (++same == 2)
+			{
+				const uint32_t run = source_get(&s);
+				if (run == 0)
+					return 0;
+				const size_t extra = run - 1;
+				if (extra > values_no - done)
+					return 0;
+				if (extra != 0)
+				{
+					if (tok->n_runs == tok->cap_runs && !tokens_reserve(tok, 0, 1))
+						return 0;
+					struct akoKagariRun* r = &tok->runs[tok->n_runs++];
+					r->out_start = (uint32_t)(out_base + done);
+					r->count = (uint32_t)extra;
+					r->after = (uint32_t)tok->n_literals;
+					r->pad = 0;
+					done += extra;
+				}
+				same = 0;
+			}
+		}
+		else
+		{
+			prev = v;
+			same = 0;
+		}
+	}
+	return (s.bitpos + 7) / 8;
+}
+
+void akoHostKagariTokensFree(struct akoKagariTokens* tok)
+{
+	free(tok->literals);
+	free(tok->runs);
+	memset(tok, 0, sizeof *tok);
 }

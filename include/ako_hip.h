@@ -126,6 +126,26 @@ int akoHipKagariEncode(akoHipPlan*, const void* d_streams, size_t image, size_t*
 int akoHipKagariFetch(akoHipPlan*, void* h_body);
 const void* akoHipKagariBody(const akoHipPlan*);
 
+/* ---- device entropy stage, decoder side: run expansion on the GPU ---------------------------------
+ * Kagari's bit-stream is sequential, so the host still parses it (library/kagari.c:296-366), but it no
+ * longer writes the coefficient stream: it hands over the literal values it decoded plus one record per
+ * run, and the GPU expands them into the stream (host work and the upload scale with the compressed size).
+ *
+ * akoHipKagariExpand   literals / runs of ALL tiles of one image (output positions are global over the
+ *                      image's stream) -> d_streams (NULL = the plan's own buffer), image `image`
+ * akoHipDecodeDownload inverse transform of the plan's own stream buffer + copy of the images to the host
+ *                      (akoHipDecodeHost without the stream upload) */
+struct akoHipKagariRun
+{
+	uint32_t out_start; /* stream index (int16 units) of the first repeated value */
+	uint32_t count;     /* how many repeats */
+	uint32_t after;     /* literals that precede the run; the repeated value is literals[after - 1] */
+	uint32_t pad;
+};
+int akoHipKagariExpand(akoHipPlan*, const int16_t* h_literals, size_t n_literals, const struct akoHipKagariRun* h_runs,
+                       size_t n_runs, void* d_streams, size_t image);
+int akoHipDecodeDownload(akoHipPlan*, void* h_images);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,8 +16,14 @@ for mode in ("device", "host"):
     t0 = time.perf_counter(); blob = api.encode(img, s); t1 = time.perf_counter()
     out[f"encode_{mode}_kagari_s"] = round(t1 - t0, 4)
     out["blob_bytes"] = int(blob.size)
-t0 = time.perf_counter(); back, _ = api.decode(blob)[:2] if isinstance(api.decode(blob), tuple) else (api.decode(blob), None); t1 = time.perf_counter()
-out["decode_s_incl_second_call"] = round(t1 - t0, 4)
+ref = None
+for mode in ("device", "host"):
+    os.environ["AKO_HIP_KAGARI"] = mode
+    t0 = time.perf_counter(); back, _ = api.decode(blob); t1 = time.perf_counter()
+    out[f"decode_{mode}_kagari_s"] = round(t1 - t0, 4)
+    assert ref is None or np.array_equal(ref, back)
+    ref = back
+os.environ["AKO_HIP_KAGARI"] = "device"
 with api.Plan(s, 4, w, h) as plan:
     d = torch.from_numpy(img).cuda().reshape(1, h, w, 4)
     st = plan.encode(d); plan.synchronize()

@@ -233,3 +233,76 @@ def test_kagari_capacity_rule_closed_form():
             out = np.zeros(cap + 8, dtype=np.uint8)
             got = L.akoHostKagariEncode(n * 2, cap, v.ctypes.data_as(V), out.ctypes.data_as(V))
             assert (got == size) if cap >= size + 1 else (got == 0), (trial, n, size, cap, got)
+
+
+def _expand_tokens(tok, n_values):
+    """numpy model of akoHipKagariExpand: literals + run records -> the value sequence."""
+    lit = np.ctypeslib.as_array(tok.literals, shape=(tok.n_literals,)).copy() if tok.n_literals else np.zeros(0, np.int16)
+    out = np.zeros(n_values, dtype=np.int16)
+    pos, used = 0, 0
+    for k in range(tok.n_runs):
+        r = tok.runs[k]
+        n = r.after - used  # literals in front of this run
+        out[pos:pos + n] = lit[used:r.after]
+        pos += n
+        used = r.after
+        assert r.out_start == pos
+        out[pos:pos + r.count] = lit[r.after - 1]
+        pos += r.count
+    out[pos:pos + (lit.size - used)] = lit[used:]
+    assert pos + lit.size - used == n_values
+    return out
+
+
+def test_kagari_tokenizer_equals_decoder():
+    """akoHostKagariTokenize + run expansion == akoHostKagariDecode, and both reject the same broken inputs."""
+    import ctypes as C
+
+    from ako_amd import api
+
+    L = api.lib()
+    V = C.c_void_p
+    rng = np.random.default_rng(5)
+    for trial in range(120):
+        n = int(rng.integers(1, 3000))
+        kind = trial % 4
+        if kind == 0:
+            v = rng.integers(-3, 4, n)
+        elif kind == 1:
+            v = np.repeat(rng.integers(-9, 9, (n + 15) // 16), 16)[:n]
+        elif kind == 2:
+            v = np.where(rng.random(n) < 0.9, 0, rng.integers(-5000, 5000, n))
+        else:
+            v = np.zeros(n)
+            v[n // 2:] = 7
+        v = np.ascontiguousarray(v.astype(np.int16))
+        packed = np.zeros(8 * n + 64, dtype=np.uint8)
+        size = L.akoHostKagariEncode(n * 2, packed.size, v.ctypes.data_as(V), packed.ctypes.data_as(V))
+        assert size > 0
+        tok = api.KagariTokens()
+        used = L.akoHostKagariTokenize(n, size, packed.ctypes.data_as(V), 0, C.byref(tok))
+        assert used == size
+        assert np.array_equal(_expand_tokens(tok, n), v)
+        assert tok.n_literals <= n and tok.n_runs <= n // 3 + 1
+        L.akoHostKagariTokensFree(C.byref(tok))
+        # damaged / truncated payloads: same verdict from both parsers
+        for cut in (size - 1, size // 2, 1):
+            if cut <= 0:
+                continue
+            bad = packed[:cut].copy()
+            out = np.zeros(n, dtype=np.int16)
+            a = L.akoHostKagariDecode(n, cut, n * 2, bad.ctypes.data_as(V), out.ctypes.data_as(V))
+            tok = api.KagariTokens()
+            b = L.akoHostKagariTokenize(n, cut, bad.ctypes.data_as(V), 0, C.byref(tok))
+            assert a == b, (trial, cut, a, b)
+            L.akoHostKagariTokensFree(C.byref(tok))
+        flip = packed[:size].copy()
+        flip[int(rng.integers(0, size))] ^= 1 << int(rng.integers(0, 8))
+        out = np.zeros(n, dtype=np.int16)
+        a = L.akoHostKagariDecode(n, size, n * 2, flip.ctypes.data_as(V), out.ctypes.data_as(V))
+        tok = api.KagariTokens()
+        b = L.akoHostKagariTokenize(n, size, flip.ctypes.data_as(V), 0, C.byref(tok))
+        assert a == b
+        if a:
+            assert np.array_equal(_expand_tokens(tok, n), out)
+        L.akoHostKagariTokensFree(C.byref(tok))

@@ -157,3 +157,49 @@ def test_device_kagari_on_real_streams_4096(po):
         head = bytes([65, 107, 111, 2]) + struct.pack("<III", 4096, 4096, 3 | (0 << 4) | (0 << 6) | (3 << 8) | (0 << 10))
         assert 16 + got.size == 559811
         assert f"{zlib.adler32(got.tobytes(), zlib.adler32(head)) & 0xFFFFFFFF:08x}" == "beeeebc6"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,ch,td", PLANS)
+@pytest.mark.parametrize("kind", ["sparse", "runs", "zeros"])
+def test_device_run_expansion_matches_host_decoder(w, h, ch, td, kind):
+    """Decoder side: host tokenizer + akoHipKagariExpand rebuilds exactly the stream that was encoded."""
+    import torch
+
+    s = api.settings(wavelet=api.CDF53, compression=api.KAGARI, q=0, g=0, tiles=td)
+    with api.Plan(s, ch, w, h) as plan:
+        n = plan.stream_bytes // 2
+        v = crafted_stream(kind, n, seed=w + 3 * ch)
+        body, bad = host_body(plan, v)
+        assert body is not None
+        streams = plan.kagari_decode_body(np.frombuffer(body, dtype=np.uint8))
+        plan.synchronize()
+        assert np.array_equal(streams.cpu().numpy().reshape(-1), v)
+        # and the pair encoder -> decoder on the device
+        streams2 = plan.kagari_decode_body(plan.kagari_encode(torch.from_numpy(v.view(np.uint8)).cuda().reshape(1, -1)))
+        assert np.array_equal(streams2.cpu().numpy().reshape(-1), v)
+
+
+@pytest.mark.gpu
+def test_device_run_expansion_rejects_forged_records():
+    import ctypes as C
+
+    s = api.settings(wavelet=api.CDF53, compression=api.KAGARI, q=0, g=0)
+    with api.Plan(s, 1, 64, 64) as plan:
+        n = plan.stream_bytes // 2
+        L = api.lib()
+        lit = (C.c_int16 * 8)(*range(8))
+        streams = plan.new_streams()
+
+        def expand(n_lit, runs):
+            arr = (api.KagariRun * max(len(runs), 1))(*[api.KagariRun(*r, 0) for r in runs])
+            return L.akoHipKagariExpand(plan._p, lit, n_lit, arr, len(runs), C.c_void_p(streams.data_ptr()), 0)
+
+        assert expand(8, [(8, n - 8, 8)]) == 0                      # 8 literals then one long run: valid
+        assert expand(8, [(8, n - 7, 8)]) != 0                      # one value too many
+        assert expand(8, [(8, n - 9, 8)]) != 0                      # one too few
+        assert expand(8, [(4, n - 8, 8)]) != 0                      # run placed where literals are
+        assert expand(8, [(8, n - 8, 9)]) != 0                      # refers to a literal that does not exist
+        assert expand(8, [(8, n - 8, 0)]) != 0
+        assert expand(8, [(2, 10, 2), (2, n - 18, 2)]) != 0         # overlapping runs
+        assert expand(8, [(2, 10, 2), (18, n - 18, 8)]) == 0
