@@ -690,26 +690,33 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		row_pitch = P.src_pitch;
 	}
 
-	// destinations
+	// destinations.  Stream and LL stores go through raw buffer resources: a lane or a row that must not
+	// store gets an out-of-range offset and the hardware drops the write (scripts/probe_buffer_store.hip;
+	// 2-byte aligned dwords are fine there too).  Every row slot therefore issues the same 4 * NPL stores
+	// with no branch around them, which keeps the compiler's vmcnt bookkeeping exact: the wait in front of
+	// a slot's pixels no longer covers the stores of the previous slot (stores count in vmcnt on gfx950).
 	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
 	const uint64_t nsub = (uint64_t)Tc * Tr;
 	const bool store_lane = (lane >= 2) && (lane < 62) && (c0 >= 0) && (c0 < Tc);
-	int16_t* ll_base[NPL];
-	int16_t* grp_base[NPL];
-	uint32_t ll_pitch = (uint32_t)Tc;
+	constexpr uint32_t OOB = 0xFFFFFFFFu;
+	constexpr int RSRC_FLAGS = 0x00020000;  // gfx9 raw buffer, 32 bit data format
+	const uint64_t stream_left = (P.stream_stride - td.stream_off) * 2;  // bytes up to the end of the image's stream
+	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(
+	    tile_stream, 0, (int)(uint32_t)(stream_left < 0xFFFFFFFFull ? stream_left : 0xFFFFFFFFull), RSRC_FLAGS);
+	int16_t* ll_root = P.ll_out_stream ? tile_stream : (P.dst + inst * P.dst_inst_stride);
+	const uint64_t ll_left = P.ll_out_stream ? stream_left : (uint64_t)P.channels * P.dst_plane_stride * 2;
+	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(
+	    ll_root, 0, (int)(uint32_t)(ll_left < 0xFFFFFFFFull ? ll_left : 0xFFFFFFFFull), RSRC_FLAGS);
+	const uint32_t ll_pitch = P.ll_out_stream ? (uint32_t)Tc : P.dst_pitch;
+	uint32_t ll_off[NPL], grp_off[NPL];  // byte offsets of this lane's column pair in row 0
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 	{
 		const int pl = p_first + p * P_STEP;
-		grp_base[p] = tile_stream + P.grp_off[pl] + 1 + c0;
-		if (P.ll_out_stream)
-			ll_base[p] = tile_stream + P.lp_off[pl] + c0;
-		else
-		{
-			ll_base[p] = P.dst + inst * P.dst_inst_stride + (uint64_t)pl * P.dst_plane_stride + c0;
-			ll_pitch = P.dst_pitch;
-		}
+		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1 + c0) * 2);
+		ll_off[p] = (uint32_t)(((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) + c0) * 2);
 	}
+	const uint32_t nsub_b = (uint32_t)(nsub * 2);
 
 	if (id.strip == 0 && id.seg == 0 && lane == 0)
 #pragma unroll
@@ -751,9 +758,18 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 
 	const int v_begin = r_lo - 3;
 	const int n_slots = r_hi + 3 - v_begin;
+	// The two slots fetched ahead of the loop are followed by as many (dropped) stores as a slot issues,
+	// so that the memory operations in flight look the same on entry as on every later trip.
+	auto phantom_stores = [&]() {
+#pragma unroll
+		for (int k = 0; k < 4 * NPL; k++)
+			__builtin_amdgcn_raw_buffer_store_b32(0u, rs_stream, OOB, 0, 0);
+	};
 	Raw ring[3];
 	fetch(v_begin, ring[0]);
+	phantom_stores();
 	fetch(v_begin + 1, ring[1]);
+	phantom_stores();
 
 	for (int base = 0; base < n_slots; base += 6)
 	{
@@ -812,22 +828,18 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				w_b[p] = pack2_inrange(quantize_f(lp[2], gf, rq), quantize_f(lp[3], gf, rq));
 				w_d[p] = pack2_inrange(quantize_f(hp[2], gf, rq), quantize_f(hp[3], gf, rq));
 			}
-			if ((r >= r_lo) && (r < r_hi))  // wave-uniform
 			{
-				if (store_lane)
-				{
+				const bool ok = store_lane && (r >= r_lo) && (r < r_hi);
+				const uint32_t rr = (P.dbg & 8) ? 0u : (uint32_t)r;  // timing experiment: every row stores to row 0
+				const uint32_t row_grp = rr * (uint32_t)Tc * 2u, row_ll = rr * ll_pitch * 2u;
 #pragma unroll
-					for (int p = 0; p < NPL; p++)
-					{
-						const uint64_t rr = (P.dbg & 8) ? 0 : (uint64_t)r;  // timing experiment: every row stores to row 0
-						int16_t* grp = grp_base[p] + rr * Tc;
-						if (P.dbg & 2)  // timing experiment: skip the stream stores
-							continue;
-						*reinterpret_cast<uint32_t*>(ll_base[p] + rr * ll_pitch) = w_ll[p];
-						*reinterpret_cast<uint32_t*>(grp) = w_c[p];
-						*reinterpret_cast<uint32_t*>(grp + nsub) = w_b[p];
-						*reinterpret_cast<uint32_t*>(grp + 2 * nsub) = w_d[p];
-					}
+				for (int p = 0; p < NPL; p++)
+				{
+					const uint32_t g0 = grp_off[p] + row_grp;
+					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, ok ? ll_off[p] + row_ll : OOB, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_c[p], rs_stream, ok ? g0 : OOB, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_b[p], rs_stream, ok ? g0 + nsub_b : OOB, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_d[p], rs_stream, ok ? g0 + 2u * nsub_b : OOB, 0, 0);
 				}
 			}
 		});
