@@ -741,9 +741,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 #pragma unroll
 		for (int par = 0; par < 2; par++)
 		{
-			int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
-			if (P.dbg & 16)  // timing experiment: every row loads row 0 / 1
-				y = par;
+			const int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
 #ifdef AKO_EXPERIMENT_NO_LOADS  // timing experiment only: wrong results
 			if (y == 12345678)
 #endif
@@ -830,7 +828,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			}
 			{
 				const bool ok = store_lane && (r >= r_lo) && (r < r_hi);
-				const uint32_t rr = (P.dbg & 8) ? 0u : (uint32_t)r;  // timing experiment: every row stores to row 0
+				const uint32_t rr = (uint32_t)r;
 				const uint32_t row_grp = rr * (uint32_t)Tc * 2u, row_ll = rr * ll_pitch * 2u;
 #pragma unroll
 				for (int p = 0; p < NPL; p++)
