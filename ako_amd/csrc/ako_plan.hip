@@ -349,11 +349,11 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
 			seg_rows = (uint32_t)atoi(e);
 	if (seg_rows == 0)
 	{
-		// aim at ~8192 waves per launch (256 CUs x 8 waves x 4 rounds).  Every segment re-reads 6 halo
-		// row slots, so big levels keep segments of >= 24 rows; small levels are latency bound
-		// (a wave's row slots are a dependent chain) and prefer many short segments
+		// aim at ~6144 waves per launch (1024 SIMDs x 3 resident waves x 2 rounds).  Every segment
+		// re-computes 6 halo row slots, so big levels keep segments of >= 24 rows; small levels are
+		// latency bound (a wave's row slots are a dependent chain) and prefer many short segments
 		const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
-		uint64_t segs = (8192 + per_seg - 1) / per_seg;
+		uint64_t segs = (6144 + per_seg - 1) / per_seg;
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);

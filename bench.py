@@ -42,7 +42,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ac
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="full8192", choices=["full8192", "batch4k", "lift4096", "tiles16k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
