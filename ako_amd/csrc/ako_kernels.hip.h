@@ -579,7 +579,24 @@ struct FormatParams
 	int32_t color, discard;
 	int16_t* stream;
 	uint64_t stream_stride;
+	// planar != 0: 'stream' is a planar int16 IMAGE instead ([image][plane][h][w], row pitch img_pitch) --
+	// the staging form in front of / behind the int16 streaming kernels for channel counts other than 4
+	uint32_t planar;
+	uint64_t plane_stride;
 };
+
+// where pixel i of a tile lives on the int16 side, and the distance between its channels
+__device__ __forceinline__ int16_t* format_plane_address(const FormatParams& P, const TileDesc& td, uint32_t image,
+                                                         uint64_t i, uint32_t x, uint32_t y, uint64_t npx, uint64_t& kstride)
+{
+	if (P.planar)
+	{
+		kstride = P.plane_stride;
+		return P.stream + (uint64_t)image * P.channels * P.plane_stride + (uint64_t)(td.y0 + y) * P.img_pitch + td.x0 + x;
+	}
+	kstride = npx;
+	return P.stream + (uint64_t)image * P.stream_stride + td.stream_off + i;
+}
 
 __global__ __launch_bounds__(THREADS) void k_format_forward(const FormatParams P)
 {
@@ -594,7 +611,8 @@ __global__ __launch_bounds__(THREADS) void k_format_forward(const FormatParams P
 	const uint32_t y = (uint32_t)(i / P.tile_w), x = (uint32_t)(i % P.tile_w);
 	const uint8_t* px = P.img + (uint64_t)image * P.img_stride +
 	                    ((uint64_t)(td.y0 + y) * P.img_pitch + (td.x0 + x)) * P.channels;
-	int16_t* out = P.stream + (uint64_t)image * P.stream_stride + td.stream_off + i;
+	uint64_t kstride;
+	int16_t* out = format_plane_address(P, td, image, i, x, y, npx, kstride);
 
 	int v[MAX_CH];
 	for (uint32_t k = 0; k < P.channels; k++)
@@ -620,7 +638,7 @@ __global__ __launch_bounds__(THREADS) void k_format_forward(const FormatParams P
 		}
 	}
 	for (uint32_t k = 0; k < P.channels; k++)
-		out[k * npx] = (int16_t)v[k];
+		out[k * kstride] = (int16_t)v[k];
 }
 
 __global__ __launch_bounds__(THREADS) void k_format_inverse(const FormatParams P)
@@ -636,11 +654,12 @@ __global__ __launch_bounds__(THREADS) void k_format_inverse(const FormatParams P
 	const uint32_t y = (uint32_t)(i / P.tile_w), x = (uint32_t)(i % P.tile_w);
 	uint8_t* px = P.img + (uint64_t)image * P.img_stride +
 	              ((uint64_t)(td.y0 + y) * P.img_pitch + (td.x0 + x)) * P.channels;
-	const int16_t* in = P.stream + (uint64_t)image * P.stream_stride + td.stream_off + i;
+	uint64_t kstride;
+	const int16_t* in = format_plane_address(P, td, image, i, x, y, npx, kstride);
 
 	int v[MAX_CH];
 	for (uint32_t k = 0; k < P.channels; k++)
-		v[k] = in[k * npx];
+		v[k] = in[k * kstride];
 	if (P.channels >= 3 && P.color != C_NONE)
 	{
 		int r, g, b;
@@ -660,6 +679,133 @@ __global__ __launch_bounds__(THREADS) void k_format_inverse(const FormatParams P
 	}
 	for (uint32_t k = 0; k < P.channels; k++)
 		px[k] = (uint8_t)sat8(v[k]);
+}
+
+// ---- planar staging, vectorised: four pixels per thread (1, 2 or 3 channels, tile width a multiple of 4) ----
+// Same arithmetic as k_format_forward / k_format_inverse with P.planar set; 4 * CH bytes in, one 8 byte
+// store per plane out (and the reverse).  Row starts may sit at any byte / element offset (odd image
+// widths): the dword accesses are made through the unaligned-capable global path like the stream stores.
+
+__device__ __forceinline__ uint32_t pack_i16x2(int lo, int hi)
+{
+	return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16);
+}
+
+template <int CH>
+__global__ __launch_bounds__(THREADS) void k_planes_forward4(const FormatParams P)
+{
+	const uint32_t qw = P.tile_w / 4;
+	const uint64_t nq = (uint64_t)qw * P.tile_h;
+	const uint64_t blocks_per_tile = (nq + THREADS - 1) / THREADS;
+	const uint64_t inst = blockIdx.x / blocks_per_tile;
+	const uint64_t i = (blockIdx.x % blocks_per_tile) * THREADS + threadIdx.x;
+	if (i >= nq)
+		return;
+	const uint32_t tile = (uint32_t)(inst % P.n_tiles), image = (uint32_t)(inst / P.n_tiles);
+	const TileDesc td = P.tiles[tile];
+	const uint32_t y = (uint32_t)(i / qw), x = (uint32_t)(i % qw) * 4;
+	const uint64_t at = (uint64_t)(td.y0 + y) * P.img_pitch + td.x0 + x;
+	const uint32_t* src = reinterpret_cast<const uint32_t*>(P.img + (uint64_t)image * P.img_stride + at * CH);
+	uint32_t w[CH];
+#pragma unroll
+	for (int k = 0; k < CH; k++)
+		w[k] = src[k];
+	int v[4][CH];
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+#pragma unroll
+		for (int c = 0; c < CH; c++)
+		{
+			const int j = p * CH + c;
+			v[p][c] = (int)((w[j >> 2] >> (8 * (j & 3))) & 255u);
+		}
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+	{
+		if constexpr (CH == 2)
+			if (P.discard && v[p][1] == 0)  // format.c:38-49,76-79
+				v[p][0] = 0;
+		if constexpr (CH == 3)
+		if (P.color != C_NONE)
+		{
+			const int r = v[p][0], g = v[p][1], b = v[p][2];
+			if (P.color == C_SUBG)
+				v[p][0] = g, v[p][1] = r - g, v[p][CH - 1] = b - g;
+			else
+			{
+				const int co = r - b;
+				const int t = b + tdiv(co, 1);
+				const int cg = g - t;
+				const int yy = t + tdiv(cg, 1);
+				v[p][0] = (P.color == C_YCOCG_Q) ? yy * 2 : yy;
+				v[p][1] = co, v[p][CH - 1] = cg;
+			}
+		}
+	}
+	int16_t* out = P.stream + (uint64_t)image * CH * P.plane_stride + at;
+#pragma unroll
+	for (int c = 0; c < CH; c++)
+		*reinterpret_cast<uint2*>(out + (uint64_t)c * P.plane_stride) =
+		    make_uint2(pack_i16x2(v[0][c], v[1][c]), pack_i16x2(v[2][c], v[3][c]));
+}
+
+template <int CH>
+__global__ __launch_bounds__(THREADS) void k_planes_inverse4(const FormatParams P)
+{
+	const uint32_t qw = P.tile_w / 4;
+	const uint64_t nq = (uint64_t)qw * P.tile_h;
+	const uint64_t blocks_per_tile = (nq + THREADS - 1) / THREADS;
+	const uint64_t inst = blockIdx.x / blocks_per_tile;
+	const uint64_t i = (blockIdx.x % blocks_per_tile) * THREADS + threadIdx.x;
+	if (i >= nq)
+		return;
+	const uint32_t tile = (uint32_t)(inst % P.n_tiles), image = (uint32_t)(inst / P.n_tiles);
+	const TileDesc td = P.tiles[tile];
+	const uint32_t y = (uint32_t)(i / qw), x = (uint32_t)(i % qw) * 4;
+	const uint64_t at = (uint64_t)(td.y0 + y) * P.img_pitch + td.x0 + x;
+	const int16_t* in = P.stream + (uint64_t)image * CH * P.plane_stride + at;
+	int v[4][CH];
+#pragma unroll
+	for (int c = 0; c < CH; c++)
+	{
+		const uint2 q = *reinterpret_cast<const uint2*>(in + (uint64_t)c * P.plane_stride);
+		v[0][c] = (int)(int16_t)(q.x & 0xFFFFu), v[1][c] = (int)q.x >> 16;
+		v[2][c] = (int)(int16_t)(q.y & 0xFFFFu), v[3][c] = (int)q.y >> 16;
+	}
+	uint32_t w[CH];
+#pragma unroll
+	for (int k = 0; k < CH; k++)
+		w[k] = 0;
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+	{
+		if constexpr (CH == 3)
+		if (P.color != C_NONE)
+		{
+			int r, g, b;
+			if (P.color == C_SUBG)
+				r = (int16_t)(v[p][1] + v[p][0]), g = v[p][0], b = (int16_t)(v[p][CH - 1] + v[p][0]);
+			else
+			{
+				const int yv = (P.color == C_YCOCG_Q) ? tdiv(v[p][0], 1) : v[p][0];
+				const int t = (int16_t)(yv - tdiv(v[p][CH - 1], 1));
+				g = (int16_t)(v[p][CH - 1] + t);
+				b = (int16_t)(t - tdiv(v[p][1], 1));
+				r = (int16_t)(b + v[p][1]);
+			}
+			v[p][0] = r, v[p][1] = g, v[p][CH - 1] = b;
+		}
+#pragma unroll
+		for (int c = 0; c < CH; c++)
+		{
+			const int j = p * CH + c;
+			w[j >> 2] |= (uint32_t)sat8(v[p][c]) << (8 * (j & 3));
+		}
+	}
+	uint32_t* dst = reinterpret_cast<uint32_t*>(P.img + (uint64_t)image * P.img_stride + at * CH);
+#pragma unroll
+	for (int k = 0; k < CH; k++)
+		dst[k] = w[k];
 }
 
 }  // namespace ako

@@ -129,6 +129,7 @@ struct akoHipPlan
 	void* d_img = nullptr;
 	void* d_stream = nullptr;
 	int32_t* d_flags = nullptr;  // overflow flags of the optimistic inverse launches
+	int16_t* planes0 = nullptr;  // planar int16 image: staging for u8 images with 1-3 or 5+ channels (staged_level0)
 	// profiling
 	bool profiling = false;
 	std::vector<EventPair> events[2];  // [0] encode launches, [1] decode launches
@@ -528,7 +529,7 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 	              (uint32_t)lt, (uint32_t)gi, units, units * 2, units * 2);
 }
 
-int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream)
+int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream, bool planar = false)
 {
 	const Group& g = pl->groups[gi];
 	FormatParams F;
@@ -538,6 +539,7 @@ int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream
 	F.img = img, F.img_stride = (uint64_t)pl->w * pl->h * pl->channels, F.img_pitch = (uint32_t)pl->w;
 	F.color = (int)pl->s.color, F.discard = pl->s.discard_non_visible;
 	F.stream = stream, F.stream_stride = pl->stream_values;
+	F.planar = planar ? 1 : 0, F.plane_stride = (uint64_t)pl->w * pl->h;
 	const uint64_t npx = (uint64_t)g.tile_w * g.tile_h;
 	const uint64_t blocks = ((npx + THREADS - 1) / THREADS) * g.tiles.size() * pl->batch;
 	if (int rc = check_blocks(blocks))
@@ -545,13 +547,60 @@ int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream
 	Launch L{pl, decode};
 	if (int rc = L.begin())
 		return rc;
-	if (decode)
+	const bool quads = planar && pl->channels <= 3 && (g.tile_w % 4) == 0;  // four pixels per thread
+	if (quads)
+	{
+		const uint64_t nq = (uint64_t)(g.tile_w / 4) * g.tile_h;
+		const uint32_t qb = (uint32_t)(((nq + THREADS - 1) / THREADS) * g.tiles.size() * pl->batch);
+#define AKO_PLANES4(CH)                                                                                 \
+	do                                                                                                  \
+	{                                                                                                   \
+		if (decode)                                                                                     \
+			hipLaunchKernelGGL(k_planes_inverse4<CH>, dim3(qb), dim3(THREADS), 0, pl->stream, F);       \
+		else                                                                                            \
+			hipLaunchKernelGGL(k_planes_forward4<CH>, dim3(qb), dim3(THREADS), 0, pl->stream, F);       \
+	} while (0)
+		if (pl->channels == 1)
+			AKO_PLANES4(1);
+		else if (pl->channels == 2)
+			AKO_PLANES4(2);
+		else
+			AKO_PLANES4(3);
+#undef AKO_PLANES4
+	}
+	else if (decode)
 		hipLaunchKernelGGL(k_format_inverse, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
 	else
 		hipLaunchKernelGGL(k_format_forward, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
 	const uint64_t units = npx * pl->channels * g.tiles.size() * pl->batch;
-	return L.end(decode ? "format_inverse" : "format_forward", 0, (uint32_t)gi, units, decode ? units * 2 : units,
-	             decode ? units : units * 2);
+	return L.end(decode ? (planar ? "planes_to_u8" : "format_inverse") : (planar ? "u8_to_planes" : "format_forward"), 0,
+	             (uint32_t)gi, units, decode ? units * 2 : units, decode ? units : units * 2);
+}
+
+// u8 images whose channel count is not 4 have no u8 streaming kernel (those split RGBA over a pair of
+// waves).  Where level 0 can stream at all they take two cheap extra passes instead of the window
+// engine: u8 -> planar int16 (deinterleave + colour) in front of the int16 streaming kernel, and the
+// reverse behind it -- the same route a PLANES_I16 plan takes, with a plan-owned staging image.
+bool staged_level0(const akoHipPlan* pl, const Group& g)
+{
+	if ((pl->flags & AKO_HIP_PLAN_PLANES_I16) || pl->channels == 4 || g.levels.empty())
+		return false;
+	if (pl->s.wavelet == AKO_WAVELET_NONE || path_mode() == PATH_GENERIC)
+		return false;
+	if (const char* e = getenv("AKO_HIP_STAGED"))
+		if (atoi(e) == 0)
+			return false;
+	const LevelGeom& L = g.levels[0];
+	return (L.cw & 3) == 0 && L.cw >= 8 && L.th >= 2 && L.tw >= 64 && L.th >= 12;
+}
+
+int ensure_planes0(akoHipPlan* pl)
+{
+	if (pl->planes0)
+		return 0;
+	if (hipMalloc((void**)&pl->planes0, pl->w * pl->h * pl->channels * pl->batch * sizeof(int16_t)) != hipSuccess)
+		return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(planar staging image) failed%s%s");
+	return 0;
 }
 
 int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
@@ -574,13 +623,21 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 		const size_t nl = g.levels.size();
 		const size_t lt = tail_start(pl, g);
 		const uint64_t insts = (uint64_t)g.tiles.size() * pl->batch;
+		const bool staged = staged_level0(pl, g) && lt > 0;
+		if (staged)
+		{
+			if (int rc = ensure_planes0(pl))
+				return rc;
+			if (int rc = run_format(pl, (int)gi, 0, (uint8_t*)d_images, pl->planes0, true))
+				return rc;
+		}
 		for (size_t l = 0; l < lt; l++)
 		{
 			const LevelGeom& L = g.levels[l];
 			LevelParams P;
 			fill_common(P, pl, g, L);
 			P.stream = (int16_t*)d_streams;
-			const bool u8 = (l == 0) && !planes;
+			const bool u8 = (l == 0) && !planes && !staged;
 			if (u8)
 			{
 				P.img = (uint8_t*)d_images;
@@ -591,7 +648,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				P.planes_per_wg = 1;
 				if (l == 0)
 				{
-					P.src = (const int16_t*)d_images;
+					P.src = staged ? pl->planes0 : (const int16_t*)d_images;
 					P.src_tiled = 1;
 					P.src_pitch = (uint32_t)pl->w;
 					P.src_plane_stride = (uint64_t)pl->w * pl->h;
@@ -689,13 +746,17 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 		if (lt < nl)
 			if (int rc = run_tail(pl, (int)gi, lt, 1, d_images, (int16_t*)d_streams))
 				return rc;
+		const bool staged = staged_level0(pl, g) && lt > 0;
+		if (staged)
+			if (int rc = ensure_planes0(pl))
+				return rc;
 		for (size_t l = lt; l-- > 0;)
 		{
 			const LevelGeom& L = g.levels[l];
 			LevelParams P;
 			fill_common(P, pl, g, L);
 			P.stream = (int16_t*)d_streams;
-			const bool u8 = (l == 0) && !planes;
+			const bool u8 = (l == 0) && !planes && !staged;
 			P.planes_per_wg = u8 ? (uint32_t)(pl->channels < 4 ? pl->channels : 4) : 1;
 			P.plane_groups = (uint32_t)((pl->channels + P.planes_per_wg - 1) / P.planes_per_wg);
 
@@ -713,7 +774,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				P.img = (uint8_t*)d_images;
 			else if (l == 0)
 			{
-				P.dst = (int16_t*)d_images;
+				P.dst = staged ? pl->planes0 : (int16_t*)d_images;
 				P.dst_tiled = 1;
 				P.dst_pitch = (uint32_t)pl->w;
 				P.dst_plane_stride = (uint64_t)pl->w * pl->h;
@@ -790,6 +851,9 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 			if (int rc = LA.end(name, (uint32_t)l, (uint32_t)gi, samples, ins * 2, samples * (u8 ? 1 : 2)))
 				return rc;
 		}
+		if (staged)
+			if (int rc = run_format(pl, (int)gi, 1, (uint8_t*)d_images, pl->planes0, true))
+				return rc;
 	}
 	return 0;
 }
@@ -959,6 +1023,8 @@ void akoHipPlanDestroy(akoHipPlan* pl)
 		(void)hipFree(pl->d_stream);
 	if (pl->d_flags)
 		(void)hipFree(pl->d_flags);
+	if (pl->planes0)
+		(void)hipFree(pl->planes0);
 	if (pl->kg)
 	{
 		KagariState* k = pl->kg;

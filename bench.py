@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="full8192", choices=["full8192", "batch4k", "lift4096", "tiles16k"])
+    ap.add_argument("--workload", default="full8192", choices=["full8192", "batch4k", "lift4096", "tiles16k", "rgb8192"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="steps in flight: consecutive steps alternate over this many HIP streams / buffer sets")
@@ -167,6 +167,8 @@ def main():
         assert h > 0, "more ranks than tile rows"
     elif args.workload == "full8192":
         w, h, ch, batch, planes = 8192, 8192, 4, 1, False
+    elif args.workload == "rgb8192":  # not a BASELINE config: three-channel images take the staged route
+        w, h, ch, batch, planes = 8192, 8192, 3, 1, False
     elif args.workload == "batch4k":
         w, h, ch, batch, planes = 3840, 2160, 4, 8, False
     else:
@@ -192,6 +194,8 @@ def main():
         host = np.stack([po.gen_plane(w * h, seed=sd).reshape(1, h, w) for sd in seeds])
     else:
         host = np.stack([po.gen_image(0, w, h, seed=sd) for sd in seeds])
+        if ch != 4:
+            host = np.ascontiguousarray(host[..., :ch])
     d_img = torch.from_numpy(host).to(dev)
     d_strs = [p.new_streams() for p in plans]
     d_backs = [p.new_images() for p in plans]
@@ -235,7 +239,7 @@ def main():
     if args.workload == "tiles16k":
         verified = bool(torch.equal(d_back, d_img))  # lossless: every rank checks its band
         assert verified, "lossless round trip failed"
-    elif rank == 0 and not planes:
+    elif rank == 0 and not planes and ch == 4:
         import zlib
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums.json")))["baseline"]
         key = "cfg2_8192_dd137_q16g16" if args.workload == "full8192" else "cfg3_4k_image0"
@@ -284,6 +288,7 @@ def main():
             "verified_against_reference_checksums": verified,
             "config": {"workload": {"full8192": "configs[2]: full path YCoCg_Q + DD13/7 + q16 + g16, one 8192x8192 "
                                                 "RGBA image per GPU, single tile, encode then decode, device resident",
+                                    "rgb8192": "extra: one 8192x8192 RGB (3 channel) image, DD13/7 q16 g16",
                                     "batch4k": "configs[3] share: 8 x 3840x2160 RGBA images per GPU, DD13/7 q16 g16",
                                     "lift4096": "configs[1]: DD13/7 lift + unlift of one 4096x4096 int16 plane",
                                     "tiles16k": "configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles 512 (AKO_BENCH_TILES), "

@@ -43,13 +43,13 @@ def hip_decode_body(body, s, ch, w, h):
 
 
 @pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt",
-                        "stream-tail1", "stream-tail2"])
+                        "stream-tail1", "stream-tail2", "stream-nostaged"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
     kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
     switches the fused in-LDS tail kernel off (AKO_HIP_TAIL=0) so every level runs as its own launch;
     '-noopt' runs the exact int16-wrapping inverse alone instead of optimistic fp32 + exact fallback."""
-    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT")}
+    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED")}
     mode = request.param
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
     # AKO_HIP_TAIL: 0 no fused tail, 1 window-engine tail, 2 segment-engine tail, unset = chosen per launch
@@ -61,6 +61,9 @@ def path_mode(request):
     elif mode.endswith("tail2"):
         os.environ["AKO_HIP_TAIL"] = "2"
     os.environ["AKO_HIP_OPT"] = "0" if mode.endswith("noopt") else "1"   # optimistic fp32 inverse on / off
+    # '-nostaged': u8 images with 1-3 / 5+ channels keep the window engine on level 0 instead of the
+    # u8 -> planar int16 staging in front of the int16 streaming kernels
+    os.environ["AKO_HIP_STAGED"] = "0" if mode.endswith("nostaged") else "1"
     yield mode
     for k, v in old.items():
         if v is None:
@@ -163,6 +166,38 @@ def test_wide_images_all_wraps(po, path_mode):
                         assert np.array_equal(dec, od), (w, h, wavelet, wrap, q)
     finally:
         os.environ.pop("AKO_HIP_SEG_ROWS", None)
+
+
+def test_staged_level0_for_1_2_3_channels(po, path_mode):
+    """u8 images that are not RGBA take the u8 -> planar int16 staging in front of the int16 streaming kernels
+    (ako_plan.hip: staged_level0): grey, grey+alpha and RGB, every colour mode, discard, odd image widths
+    (rows of the staging image then start at odd element offsets), tiles (interior tiles staged, edge tiles on
+    the window engine) and adversarial streams on the way back."""
+    nrng = np.random.default_rng(33)
+    cases = [(1, 256, 96, 0), (2, 516, 64, 0), (3, 1000, 66, 0), (3, 1001, 131, 128), (1, 515, 200, 64),
+             (2, 300, 200, 128), (3, 640, 130, 256), (5, 256, 64, 0)]
+    for (ch, w, h, td) in cases:
+        for (wavelet, wrap, color, q, g, discard) in ((0, 0, 0, 16, 16, 0), (1, 1, 1, 0, 0, 1), (2, 2, 2, 7, 0, 0),
+                                                     (0, 3, 0, 0, 0, 0), (1, 0, 0, 40, 9, 1)):
+            img = nrng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+            if ch in (2, 4):
+                img[nrng.random((h, w)) < 0.2, ch - 1] = 0  # transparent pixels for 'discard'
+            s = po.settings(wavelet=wavelet, wrap=wrap, color=color, compression=2, q=q, g=g, tiles=td,
+                            discard=discard)
+            ob, st = po.encode_image(s, img)
+            assert st == 0
+            body = hip_encode_body(img, s)
+            assert np.array_equal(body, ob[16:]), (ch, w, h, td, wavelet, wrap, color, q)
+            od, os_, _ = po.decode_image(ob)
+            dec = hip_decode_body(ob[16:], os_, ch, w, h)
+            assert np.array_equal(dec, od), (ch, w, h, td, wavelet, wrap, color, q)
+            # full-range coefficients: every int16 wrap of the inverse must agree as well
+            junk = ob.copy()
+            junk[16:] = nrng.integers(0, 256, junk.size - 16, dtype=np.uint8)
+            od2, os2, st2 = po.decode_image(junk)
+            if st2 == 0 and od2 is not None:
+                dec2 = hip_decode_body(junk[16:], os2, ch, w, h)
+                assert np.array_equal(dec2, od2), ("adversarial", ch, w, h, td, wavelet, wrap, color)
 
 
 def test_adversarial_streams_decode_alike(po, path_mode):
