@@ -329,6 +329,11 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 		return false;
 	if (u8 && pl->channels != 4)
 		return false;
+	// the forward streaming kernels address a tile's stream and the LL scratch planes with 32-bit byte
+	// offsets (raw buffer stores): tiles of 4 GiB and more stay on the window engine
+	for (const Group& g : pl->groups)
+		if (g.tile_values * 2 >= 0xFFF00000ull || (uint64_t)g.tile_w * g.tile_h * pl->channels * 2 >= 0xFFF00000ull)
+			return false;
 	if (mode == PATH_STREAM)
 		return true;
 	// a launch over many planes (tiled images, batches of tiles) fills the chip at any level size, and the
