@@ -343,7 +343,7 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 	return L.tw >= 64 && L.th >= 12;
 }
 
-StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
+StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit, bool u8)
 {
 	StreamGeom G;
 	G.strips = (L.tw + SNET - 1) / SNET;
@@ -355,11 +355,12 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit)
 			seg_rows = (uint32_t)atoi(e);
 	if (seg_rows == 0)
 	{
-		// aim at ~6144 waves per launch (1024 SIMDs x 3 resident waves x 2 rounds).  Every segment
-		// re-computes 6 halo row slots, so big levels keep segments of >= 24 rows; small levels are
-		// latency bound (a wave's row slots are a dependent chain) and prefer many short segments
+		// aim at two rounds of resident waves: the u8 kernels run 3 waves per SIMD (6144 waves), the int16
+		// ones 5 (10240).  Every segment re-computes 6 halo row slots, so big levels keep segments of >= 24
+		// rows; small levels are latency bound (a wave's row slots are a dependent chain) and prefer many
+		// short segments.  Rounded DOWN: a handful of waves over the target would cost a third round
 		const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
-		uint64_t segs = (6144 + per_seg - 1) / per_seg;
+		uint64_t segs = (u8 ? 6144 : 10240) / per_seg;
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
@@ -687,7 +688,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
-				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
+				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts, u8);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
 				if (int rc = check_blocks(blocks))
@@ -801,7 +802,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
-				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts);
+				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts, u8);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint32_t waves_per_block = u8 ? 2 : (THREADS / 64);
 				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
