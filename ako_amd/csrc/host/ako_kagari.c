@@ -120,37 +120,59 @@ size_t akoHostKagariEncode(size_t input_bytes, size_t capacity, const void* inpu
 
 /* ---- decoder ------------------------------------------------------------------------------- */
 
+/* The reference's reader (kagari.c:113-163) refills a 64 bit accumulator EAGERLY, whole bytes at a time, and
+ * reports the bytes it has FETCHED as the size it consumed -- which compression.c:69 then compares with the
+ * block size.  For a stream the encoder wrote the two always agree; for a damaged one the verdict depends on
+ * the fetch pattern, so the pattern is part of the format's observable behaviour and is kept as is:
+ * refill when fewer than 32 bits are held (or the accumulator is all zero), up to at least 56 bits. */
 struct bit_source
 {
+	uint64_t acc;
+	int held; /* valid high bits of acc */
+	const uint8_t* at;
+	const uint8_t* end;
 	const uint8_t* base;
-	size_t bytes;
-	size_t bitpos;
 };
 
-/* next 32 bits at bitpos, zero padded past the end */
-static inline uint32_t source_peek(const struct bit_source* s)
+/* Next gamma code, low 16 bits (kagari.c keeps it in a uint16_t, so an over-long code simply wraps).
+ * Returns 0 when the stream ends or breaks, 1 otherwise. */
+static inline int source_get(struct bit_source* s, uint16_t* value)
 {
-	const size_t byte = s->bitpos >> 3;
-	uint64_t w = 0;
-	for (size_t k = 0; k < 5; k++)
-		w = (w << 8) | ((byte + k < s->bytes) ? s->base[byte + k] : 0);
-	return (uint32_t)(w >> (8 - (s->bitpos & 7)));
+	if (s->acc == 0 || s->held < 32)
+	{
+		if (s->at + ((64 - s->held) / 8) < s->end)
+		{
+			do
+			{
+				s->held += 8;
+				s->acc |= (uint64_t)(*s->at++) << ((64 - s->held) & 63);
+			} while (s->held < 56);
+		}
+		else
+		{
+			while (s->held < 56 && s->at < s->end)
+			{
+				s->held += 8;
+				s->acc |= (uint64_t)(*s->at++) << (64 - s->held);
+			}
+		}
+		if (s->acc == 0)
+			return 0;
+	}
+	const uint32_t top = (uint32_t)(s->acc >> 32);
+	const int zeros = top ? __builtin_clz(top) : 32;
+	const int bits = 2 * zeros + 1;
+	if (bits > s->held)
+		return 0;
+	*value = (uint16_t)(s->acc >> (64 - bits));
+	s->acc = (bits < 64) ? (s->acc << bits) : 0;
+	s->held -= bits;
+	return 1;
 }
 
-/* gamma code -> value (1..65535), or 0 on a broken stream */
-static inline uint32_t source_get(struct bit_source* s)
+static inline size_t source_used(const struct bit_source* s)
 {
-	const uint32_t w = source_peek(s);
-	if (w == 0)
-		return 0;
-	const int zeros = __builtin_clz(w);
-	if (zeros > 15)
-		return 0;
-	const int bits = 2 * zeros + 1;
-	if (s->bitpos + (size_t)bits > s->bytes * 8)
-		return 0;
-	s->bitpos += (size_t)bits;
-	return w >> (32 - bits);
+	return (size_t)(s->at - s->base);
 }
 
 size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_bytes, const void* input, void* output)
@@ -160,7 +182,7 @@ size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_b
 	if (values_no > output_bytes / 2)
 		return 0;
 
-	struct bit_source s = {input, input_bytes, 0};
+	struct bit_source s = {0, 0, input, (const uint8_t*)input + input_bytes, input};
 	int16_t* out = output;
 	size_t done = 0;
 	int16_t prev = 0;
@@ -168,8 +190,8 @@ size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_b
 
 	while (done < values_no)
 	{
-		const uint32_t code = source_get(&s);
-		if (code == 0)
+		uint16_t code;
+		if (!source_get(&s, &code))
 			return 0;
 		const uint16_t zz = (uint16_t)(code - 1);
 		const int16_t v = (int16_t)((zz >> 1) ^ (uint16_t)(~(zz & 1) + 1)); /* kagari.c:175-178 */
@@ -179,10 +201,12 @@ size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_b
 		{
 			if (++same == 2)
 			{
-				const uint32_t run = source_get(&s);
-				if (run == 0)
+				uint16_t run;
+				if (!source_get(&s, &run))
 					return 0;
-				const size_t extra = run - 1;
+				const size_t extra = (uint16_t)(run - 1);
+				/* the reference lets a run overshoot the value count (its counter wraps, kagari.c:345-353) and
+				 * then fails further on, at the latest at the end of its output buffer: same verdict here */
 				if (extra > values_no - done)
 					return 0;
 				for (size_t k = 0; k < extra; k++)
@@ -197,7 +221,7 @@ size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_b
 			same = 0;
 		}
 	}
-	return (s.bitpos + 7) / 8;
+	return source_used(&s);
 }
 
 
@@ -239,15 +263,15 @@ size_t akoHostKagariTokenize(size_t values_no, size_t input_bytes, const void* i
 	if (input_bytes == 0 || values_no == 0 || out_base + values_no > 0xFFFFFFF0ull)
 		return 0;
 
-	struct bit_source s = {input, input_bytes, 0};
+	struct bit_source s = {0, 0, input, (const uint8_t*)input + input_bytes, input};
 	size_t done = 0;
 	int16_t prev = 0;
 	unsigned same = 0;
 
 	while (done < values_no)
 	{
-		const uint32_t code = source_get(&s);
-		if (code == 0)
+		uint16_t code;
+		if (!source_get(&s, &code))
 			return 0;
 		const uint16_t zz = (uint16_t)(code - 1);
 		const int16_t v = (int16_t)((zz >> 1) ^ (uint16_t)(~(zz & 1) + 1));
@@ -260,10 +284,10 @@ size_t akoHostKagariTokenize(size_t values_no, size_t input_bytes, const void* i
 		{
 			if (++same == 2)
 			{
-				const uint32_t run = source_get(&s);
-				if (run == 0)
+				uint16_t run;
+				if (!source_get(&s, &run))
 					return 0;
-				const size_t extra = run - 1;
+				const size_t extra = (uint16_t)(run - 1);
 				if (extra > values_no - done)
 					return 0;
 				if (extra != 0)
@@ -286,7 +310,7 @@ size_t akoHostKagariTokenize(size_t values_no, size_t input_bytes, const void* i
 			same = 0;
 		}
 	}
-	return (s.bitpos + 7) / 8;
+	return source_used(&s);
 }
 
 void akoHostKagariTokensFree(struct akoKagariTokens* tok)

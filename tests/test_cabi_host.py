@@ -306,3 +306,57 @@ def test_kagari_tokenizer_equals_decoder():
         if a:
             assert np.array_equal(_expand_tokens(tok, n), out)
         L.akoHostKagariTokensFree(C.byref(tok))
+
+
+def test_kagari_decoder_verdicts_on_damaged_payloads_match_the_oracle(po):
+    """compression.c:69 accepts a block only when the decoder reports exactly the block size as consumed, and
+    kagari.c reports the bytes its eager reader FETCHED: on damaged payloads the verdict depends on that fetch
+    pattern.  Host decoder, host tokenizer and oracle must agree on every input (the oracle is pinned against
+    the compiled reference in tests/test_oracle_vs_ref.py)."""
+    L, O = api.lib(), po.lib()
+    V = C.c_void_p
+    O.orcKagariDecode.restype = C.c_size_t
+    O.orcKagariDecode.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, V, V]
+    rng = np.random.default_rng(2024)
+    agree_nonzero = 0
+    for trial in range(400):
+        n = int(rng.integers(2, 1500))
+        kind = trial % 3
+        if kind == 0:
+            v = np.where(rng.random(n) < 0.85, 0, rng.integers(-900, 900, n))
+        elif kind == 1:
+            v = np.repeat(rng.integers(-20, 20, (n + 5) // 6), 6)[:n]
+        else:
+            v = rng.integers(-4, 5, n)
+        v = np.ascontiguousarray(v.astype(np.int16))
+        packed = np.zeros(8 * n + 64, dtype=np.uint8)
+        size = L.akoHostKagariEncode(n * 2, packed.size, v.ctypes.data_as(V), packed.ctypes.data_as(V))
+        assert size > 0
+        for damage in range(6):
+            bad = packed[:size].copy()
+            length = size
+            if damage < 3:
+                bad[int(rng.integers(0, size))] ^= 1 << int(rng.integers(0, 8))
+            elif damage == 3:
+                at = int(rng.integers(0, size))
+                bad[at:at + 3] = rng.integers(0, 256, bad[at:at + 3].size, dtype=np.uint8)
+            elif damage == 4:
+                length = int(rng.integers(1, size + 1))
+            else:
+                bad = np.concatenate([bad, rng.integers(0, 256, 5, dtype=np.uint8)])  # trailing garbage inside the block
+                length = bad.size
+            bad = np.ascontiguousarray(bad)
+            for values in (n, n + 1, max(1, n - 1)):  # also a wrong expected count
+                cap = 2 * values + 2 * 64  # what decode.c:152 hands over: plane bytes + spacing
+                o1 = np.zeros(cap // 2 + 8, dtype=np.int16)
+                o2 = np.zeros(cap // 2 + 8, dtype=np.int16)
+                a = L.akoHostKagariDecode(values, length, 2 * values, bad.ctypes.data_as(V), o1.ctypes.data_as(V))
+                b = O.orcKagariDecode(values, length, cap, bad.ctypes.data_as(V), o2.ctypes.data_as(V))
+                tok = api.KagariTokens()
+                c = L.akoHostKagariTokenize(values, length, bad.ctypes.data_as(V), 0, C.byref(tok))
+                L.akoHostKagariTokensFree(C.byref(tok))
+                assert a == b == c, (trial, damage, values, a, b, c)
+                if a:
+                    agree_nonzero += 1
+                    assert np.array_equal(o1[:values], o2[:values])
+    assert agree_nonzero > 50  # damaged-but-accepted streams were among them

@@ -438,6 +438,68 @@ def test_api_error_statuses(po):
     api.lib().akoDefaultFree(out)
 
 
+@pytest.mark.parametrize("route", ["device", "host"])
+def test_api_damaged_kagari_blobs_behave_like_the_oracle(po, route):
+    """Bit flips, truncations and forged block sizes in real .ako blobs: akoDecodeExt (entropy stage on the
+    device route or on the host) must accept / reject exactly what the oracle's decoder does and return the
+    same pixels when it accepts -- and the GPU must never be handed an inconsistent run list."""
+    old = os.environ.get("AKO_HIP_KAGARI")
+    os.environ["AKO_HIP_KAGARI"] = route
+    try:
+        nrng = np.random.default_rng(101)
+        for (w, h, ch, td, wavelet) in [(64, 64, 4, 0, 0), (100, 75, 3, 32, 1), (51, 41, 1, 0, 2), (256, 96, 4, 64, 0)]:
+            img = po.gen_image(0, w, h)[:, :, :ch].copy()
+            s = po.settings(wavelet=wavelet, compression=0, q=12, g=4, tiles=td)
+            blob, st = po.encode_image(s, img)
+            assert st == 0
+            for trial in range(60):
+                bad = blob.copy()
+                kind = trial % 4
+                if kind == 0:    # one flipped bit anywhere behind the head
+                    at = int(nrng.integers(16, bad.size))
+                    bad[at] ^= 1 << int(nrng.integers(0, 8))
+                elif kind == 1:  # truncated
+                    bad = bad[:int(nrng.integers(17, bad.size))]
+                elif kind == 2:  # a burst of noise
+                    at = int(nrng.integers(16, bad.size - 4))
+                    bad[at:at + 4] = nrng.integers(0, 256, 4, dtype=np.uint8)
+                else:            # forged size of the first block
+                    bad[16:20] = np.frombuffer(np.uint32(int(nrng.integers(0, 2 * bad.size))).tobytes(), np.uint8)
+                try:
+                    got, _ = api.decode(bad)
+                    got_st = 0
+                except api.AkoError as e:
+                    got, got_st = None, e.status
+                # The reference (and so the oracle) never checks a compressed block against the end of the
+                # input (library/decode.c:148-150) and would read past it: those cases are not given to the
+                # oracle; the product must refuse them as broken input.
+                n_tiles = 1 if td == 0 else ((w + td - 1) // td) * ((h + td - 1) // td)
+                cursor, runs_off_the_end = 16, False
+                for _ in range(n_tiles):
+                    if cursor + 4 > bad.size:
+                        runs_off_the_end = True
+                        break
+                    block = int(np.frombuffer(bad[cursor:cursor + 4].tobytes(), "<u4")[0])
+                    if cursor + 4 + block > bad.size:
+                        runs_off_the_end = True
+                        break
+                    cursor += 4 + block
+                if runs_off_the_end:
+                    assert got is None and got_st == 15, (w, h, ch, td, trial, got_st)
+                    continue
+                want, _, want_st = po.decode_image(bad)
+                assert (want is None) == (got is None), (w, h, ch, td, trial, want_st, got_st)
+                if want is not None:
+                    assert np.array_equal(want, got), (w, h, ch, td, trial)
+                else:
+                    assert got_st == want_st, (w, h, ch, td, trial, want_st, got_st)
+    finally:
+        if old is None:
+            os.environ.pop("AKO_HIP_KAGARI", None)
+        else:
+            os.environ["AKO_HIP_KAGARI"] = old
+
+
 def test_profiling_records(po):
     img = po.gen_image(0, 512, 512)
     with api.Plan(api.settings(wavelet=0, compression=2, q=16, g=16), 4, 512, 512) as plan:

@@ -158,3 +158,56 @@ def test_kagari_bitstreams(po):
             d = np.zeros(n, np.int16)
             assert L.orcKagariDecode(n, a, n * 2, o1.ctypes.data_as(V), d.ctypes.data_as(V)) == a
             assert np.array_equal(d, v)
+
+
+def test_kagari_decoder_on_damaged_payloads(po):
+    """The oracle's decoder against the reference's on bit flips, noise, truncation, trailing garbage and a
+    wrong expected count: same 'bytes consumed' (the figure compression.c:69 compares with the block size)
+    and the same values when it is non-zero."""
+    R, L = po.ref(), po.lib()
+    V = C.c_void_p
+    for lib, name in ((R, "akoKagariDecode"), (L, "orcKagariDecode")):
+        getattr(lib, name).restype = C.c_size_t
+        getattr(lib, name).argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, V, V]
+    R.akoKagariEncode.restype = C.c_size_t
+    R.akoKagariEncode.argtypes = [C.c_size_t, C.c_size_t, V, V]
+    rng = np.random.default_rng(77)
+    accepted = 0
+    for trial in range(400):
+        n = int(rng.integers(2, 1500))
+        kind = trial % 3
+        if kind == 0:
+            v = np.where(rng.random(n) < 0.85, 0, rng.integers(-900, 900, n))
+        elif kind == 1:
+            v = np.repeat(rng.integers(-20, 20, (n + 5) // 6), 6)[:n]
+        else:
+            v = rng.integers(-4, 5, n)
+        v = np.ascontiguousarray(v.astype(np.int16))
+        packed = np.zeros(8 * n + 64, dtype=np.uint8)
+        size = R.akoKagariEncode(n * 2, packed.size, v.ctypes.data_as(V), packed.ctypes.data_as(V))
+        assert size > 0
+        for damage in range(6):
+            bad = packed[:size].copy()
+            length = size
+            if damage < 3:
+                bad[int(rng.integers(0, size))] ^= 1 << int(rng.integers(0, 8))
+            elif damage == 3:
+                at = int(rng.integers(0, size))
+                bad[at:at + 3] = rng.integers(0, 256, bad[at:at + 3].size, dtype=np.uint8)
+            elif damage == 4:
+                length = int(rng.integers(1, size + 1))
+            else:
+                bad = np.concatenate([bad, rng.integers(0, 256, 5, dtype=np.uint8)])
+                length = bad.size
+            bad = np.ascontiguousarray(np.concatenate([bad, np.zeros(16, np.uint8)]))  # slack behind the payload
+            for values in (n, n + 1, max(1, n - 1)):
+                cap = 2 * values + 2 * 64
+                o1 = np.zeros(cap // 2 + 8, dtype=np.int16)
+                o2 = np.zeros(cap // 2 + 8, dtype=np.int16)
+                a = R.akoKagariDecode(values, length, cap, bad.ctypes.data_as(V), o1.ctypes.data_as(V))
+                b = L.orcKagariDecode(values, length, cap, bad.ctypes.data_as(V), o2.ctypes.data_as(V))
+                assert a == b, (trial, damage, values, a, b)
+                if a:
+                    accepted += 1
+                    assert np.array_equal(o1[:values], o2[:values])
+    assert accepted > 50
