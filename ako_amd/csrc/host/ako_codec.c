@@ -34,6 +34,62 @@ static int chosen_device(void)
 	return (e != NULL && *e != '\0') ? atoi(e) : 0;
 }
 
+/* ---- plan cache ----------------------------------------------------------------------------
+ * Creating a plan allocates the device buffers of the transform and of the entropy stage (a few dozen
+ * hipMalloc / hipFree per call, about half a millisecond -- more than the work on a small image).
+ * Each thread keeps the plan of its last call and reuses it when the next call has the same shape and
+ * settings (the usual case: a stream of equally sized images, akoenc's ratio search).  The plan of a
+ * thread is replaced on a miss and lives until then: AKO_HIP_PLAN_CACHE=0 switches the cache off and
+ * restores create / destroy per call.  Re-entrancy is unaffected (nothing is shared between threads). */
+struct plan_key
+{
+	struct akoSettings s;
+	size_t channels, w, h;
+	int device;
+};
+
+/* one slot per direction: an encoder's settings never equal a decoder's (quantization is not in the head) */
+static __thread akoHipPlan* cached_plans[2] = {NULL, NULL};
+static __thread struct plan_key cached_keys[2];
+
+static int plan_cache_on(void)
+{
+	const char* e = getenv("AKO_HIP_PLAN_CACHE");
+	return !(e != NULL && atoi(e) == 0);
+}
+
+static akoHipPlan* plan_acquire(int slot, const struct akoSettings* st, size_t channels, size_t w, size_t h,
+                                enum akoStatus* status)
+{
+	struct plan_key key;
+	memset(&key, 0, sizeof key); /* padding bytes too: the keys are compared with memcmp */
+	key.s.wavelet = st->wavelet, key.s.color = st->color, key.s.wrap = st->wrap, key.s.compression = st->compression;
+	key.s.tiles_dimension = st->tiles_dimension, key.s.quantization = st->quantization, key.s.gate = st->gate;
+	key.s.chroma_loss = st->chroma_loss, key.s.discard_non_visible = st->discard_non_visible;
+	key.channels = channels, key.w = w, key.h = h, key.device = chosen_device();
+
+	if (cached_plans[slot] != NULL)
+	{
+		akoHipPlan* p = cached_plans[slot];
+		cached_plans[slot] = NULL; /* taken out while in use: an event callback may call back into the library */
+		if (plan_cache_on() && memcmp(&key, &cached_keys[slot], sizeof key) == 0)
+			return p;
+		akoHipPlanDestroy(p);
+	}
+	cached_keys[slot] = key;
+	return akoHipPlanCreate(key.device, st, channels, w, h, 1, NULL, 0, status);
+}
+
+static void plan_release(int slot, akoHipPlan* plan, int healthy)
+{
+	if (plan == NULL)
+		return;
+	if (healthy && plan_cache_on() && cached_plans[slot] == NULL)
+		cached_plans[slot] = plan; /* its key was stored by plan_acquire */
+	else
+		akoHipPlanDestroy(plan);
+}
+
 static void complain(const char* where)
 {
 	/* failing loudly: a missing / broken HIP path must never pass for a working codec */
@@ -77,7 +133,7 @@ AKO_API size_t akoEncodeExt(const struct akoCallbacks* c, const struct akoSettin
 	if ((status = akoHostHeadWrite(channels, image_w, image_h, &st, blob)) != AKO_OK)
 		goto failure;
 
-	if ((plan = akoHipPlanCreate(chosen_device(), &st, channels, image_w, image_h, 1, NULL, 0, &status)) == NULL)
+	if ((plan = plan_acquire(0, &st, channels, image_w, image_h, &status)) == NULL)
 	{
 		complain("akoEncodeExt");
 		goto failure;
@@ -234,7 +290,7 @@ AKO_API size_t akoEncodeExt(const struct akoCallbacks* c, const struct akoSettin
 	}
 
 done:
-	akoHipPlanDestroy(plan);
+	plan_release(0, plan, 1);
 	if (streams != NULL)
 		cb.free(streams);
 	if (packed != NULL)
@@ -249,8 +305,7 @@ done:
 	return blob_size;
 
 failure:
-	if (plan != NULL)
-		akoHipPlanDestroy(plan);
+	plan_release(0, plan, 0); /* after an error the plan is not kept */
 	if (cb.free != NULL)
 	{
 		if (streams != NULL)
@@ -299,7 +354,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	if ((status = akoHostHeadRead(input, &channels, &image_w, &image_h, &st)) != AKO_OK)
 		goto failure;
 
-	if ((plan = akoHipPlanCreate(chosen_device(), &st, channels, image_w, image_h, 1, NULL, 0, &status)) == NULL)
+	if ((plan = plan_acquire(1, &st, channels, image_w, image_h, &status)) == NULL)
 	{
 		complain("akoDecodeExt");
 		goto failure;
@@ -449,7 +504,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	}
 
 decoded:
-	akoHipPlanDestroy(plan);
+	plan_release(1, plan, 1);
 	if (streams != NULL)
 		cb.free(streams);
 
@@ -467,8 +522,7 @@ decoded:
 
 failure:
 	akoHostKagariTokensFree(&tokens);
-	if (plan != NULL)
-		akoHipPlanDestroy(plan);
+	plan_release(1, plan, 0);
 	if (cb.free != NULL)
 	{
 		if (streams != NULL)

@@ -512,6 +512,53 @@ def test_api_damaged_kagari_blobs_behave_like_the_oracle(po, route):
             os.environ["AKO_HIP_KAGARI"] = old
 
 
+def test_api_plan_cache_and_threads(po):
+    """akoEncodeExt / akoDecodeExt keep the plan of the previous call per thread (ako_codec.c): alternating
+    shapes and settings, cache on and off, and several threads at once must all give the oracle's bytes."""
+    import threading
+
+    cases = []
+    for (w, h, ch, q, td, wavelet) in [(64, 64, 4, 16, 0, 0), (100, 75, 3, 0, 32, 1), (64, 64, 4, 16, 0, 0),
+                                       (64, 64, 4, 9, 0, 0), (256, 96, 4, 16, 64, 0), (51, 41, 1, 16, 0, 2)]:
+        img = po.gen_image(0, w, h)[:, :, :ch].copy()
+        s = po.settings(wavelet=wavelet, compression=0, q=q, g=0, tiles=td)
+        blob, st = po.encode_image(s, img)
+        assert st == 0
+        dec, _, _ = po.decode_image(blob)
+        cases.append((img, api.settings(wavelet=wavelet, compression=0, q=q, g=0, tiles=td), blob, dec))
+
+    def run_all(rounds, errors):
+        try:
+            for r in range(rounds):
+                for (img, s, blob, dec) in cases:
+                    assert np.array_equal(api.encode(img, s), blob)
+                    got, _ = api.decode(blob)
+                    assert np.array_equal(got, dec)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    old = os.environ.get("AKO_HIP_PLAN_CACHE")
+    try:
+        for mode in ("1", "0"):
+            os.environ["AKO_HIP_PLAN_CACHE"] = mode
+            errors = []
+            run_all(3, errors)
+            assert not errors, errors
+        os.environ["AKO_HIP_PLAN_CACHE"] = "1"
+        errors = []
+        threads = [threading.Thread(target=run_all, args=(2, errors)) for _ in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+    finally:
+        if old is None:
+            os.environ.pop("AKO_HIP_PLAN_CACHE", None)
+        else:
+            os.environ["AKO_HIP_PLAN_CACHE"] = old
+
+
 def test_profiling_records(po):
     img = po.gen_image(0, 512, 512)
     with api.Plan(api.settings(wavelet=0, compression=2, q=16, g=16), 4, 512, 512) as plan:
