@@ -283,7 +283,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.workload == "tiles16k" else "weak",
             "vs_baseline": None,
-            "dtype": "int16 storage / int32 arithmetic",
+            "dtype": "int32",
+            "dtype_note": "int32 arithmetic with int16 narrowing exactly where the reference narrows (int16 storage); "
+                          "carried out on the fp32 pipe where every value is provably an exact small integer",
             "data": "synthetic",
             "verified_against_reference_checksums": verified,
             "config": {"workload": {"full8192": "configs[2]: full path YCoCg_Q + DD13/7 + q16 + g16, one 8192x8192 "
