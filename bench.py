@@ -325,7 +325,7 @@ def main():
                          "isolated_ms": round(sum(iso[k]) / len(iso[k]), 4) if k in iso else None}
                         for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
