@@ -320,12 +320,26 @@ bool many_planes(const akoHipPlan* pl)
 // streaming kernels need a level width that is a multiple of 4 (no phantom column, and an even
 // number of coefficient columns so that a lane's column pair is never split by the border);
 // in AUTO mode they are used where they pay: wide levels
+// Level widths the streaming kernels take: multiples of 4 (an even number of coefficient columns, no phantom
+// sample), and 2 mod 4 where the last strip can shift by one column (lane_columns() in ako_stream.hip.h):
+// at least two strips, not REPEAT.  Odd widths (phantom last sample) stay on the window engine.
+bool stream_width_ok(const akoHipPlan* pl, const LevelGeom& L)
+{
+	if ((L.cw & 1) != 0 || L.cw < 8)
+		return false;
+	if ((L.cw & 3) == 0)
+		return true;
+	// ... and a last strip of three columns or more (tw odd: tw % SNET is 1, 3, 5, ...): with a single
+	// column the strip before it would need border values inside its own net range
+	return L.tw > (uint32_t)SNET && (L.tw % SNET) != 1 && pl->s.wrap != AKO_WRAP_REPEAT;
+}
+
 bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 {
 	const int mode = path_mode();
 	if (mode == PATH_GENERIC)
 		return false;
-	if ((L.cw & 3) != 0 || L.cw < 8 || L.th < 2)
+	if (!stream_width_ok(pl, L) || L.th < 2)
 		return false;
 	if (u8 && pl->channels != 4)
 		return false;
@@ -553,7 +567,7 @@ int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream
 	Launch L{pl, decode};
 	if (int rc = L.begin())
 		return rc;
-	const bool quads = planar && pl->channels <= 3 && (g.tile_w % 4) == 0;  // four pixels per thread
+	const bool quads = planar && pl->channels <= 3 && (g.tile_w % 4) == 0;  // four pixels per thread (else one)
 	if (quads)
 	{
 		const uint64_t nq = (uint64_t)(g.tile_w / 4) * g.tile_h;
@@ -597,7 +611,7 @@ bool staged_level0(const akoHipPlan* pl, const Group& g)
 		if (atoi(e) == 0)
 			return false;
 	const LevelGeom& L = g.levels[0];
-	return (L.cw & 3) == 0 && L.cw >= 8 && L.th >= 2 && L.tw >= 64 && L.th >= 12;
+	return stream_width_ok(pl, L) && L.th >= 2 && L.tw >= 64 && L.th >= 12;
 }
 
 int ensure_planes0(akoHipPlan* pl)

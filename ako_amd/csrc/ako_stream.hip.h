@@ -180,6 +180,7 @@ struct HEdge
 	bool left, right;   // this strip holds out-of-range lanes on that side (never set for REPEAT)
 	bool oob_l, oob_r;  // this lane is such a lane
 	bool first, last;   // this lane holds columns 0,1 / T-2,T-1
+	bool half;          // this lane holds column T-1 in its FIRST slot (odd T, strip not shifted): see lane_columns()
 	int lane_first, lane_last;
 	int wrap;
 };
@@ -440,10 +441,16 @@ struct LaneCols
 	bool hedge;
 };
 
-__device__ __forceinline__ LaneCols lane_columns(uint32_t strip, int lane, int Tc, int wrap)
+// An ODD number of coefficient columns (level width = 2 mod 4) would leave the last column alone in the
+// first slot of a lane.  Instead the LAST strip starts one column earlier: its lanes then hold (odd, even)
+// pairs, the last two columns share a lane exactly as with an even count, and all the border logic
+// applies unchanged.  The strip re-computes the last net column of its left neighbour and stores the same
+// values over it.  Needs a left neighbour (two strips at least) and a wrap mode that does not pair up
+// columns across the border (REPEAT does): see stream_width_ok() in ako_plan.hip.
+__device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips, int lane, int Tc, int wrap)
 {
 	LaneCols lc;
-	const int c_base = (int)strip * SNET - SORG;
+	const int c_base = (int)strip * SNET - SORG - (((Tc & 1) && strip + 1 == strips) ? 1 : 0);
 	lc.c0 = c_base + 2 * lane;
 	lc.he.wrap = wrap;
 	lc.he.left = (wrap != W_REPEAT) && (c_base < 0);
@@ -454,7 +461,12 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, int lane, int T
 	lc.he.lane_last = (Tc - 2 - c_base) / 2;
 	lc.he.first = (lc.c0 == 0);
 	lc.he.last = (lc.c0 == Tc - 2);
-	lc.hedge = lc.he.left || lc.he.right;
+	// Odd Tc, in a strip that is not the (shifted) last one: the lane at c0 == Tc - 1 would straddle the border.
+	// Its loads are clamped to the pair (Tc - 2, Tc - 1); the callers then move the second value into the first
+	// slot.  The lane's second slot (column Tc) is never needed: stream_width_ok() only admits widths whose
+	// last strip holds three columns or more, which keeps this strip's net outputs clear of the border.
+	lc.he.half = (lc.c0 == Tc - 1);
+	lc.hedge = lc.he.left || lc.he.right;  // (a half lane only exists where he.right is set)
 	if (wrap == W_REPEAT)
 		lc.cs = max(map_index(lc.c0, Tc, W_REPEAT) & ~1, 0);  // pairs stay together: c0 and Tc are even
 	else
@@ -801,6 +813,10 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					smp[par][0][2] = zero_row ? (V)0 : (V)lo16(raw.a[par].y);
 					smp[par][0][3] = zero_row ? (V)0 : (V)hi16(raw.a[par].y);
 				}
+				if (HEDGE && lc.he.half)
+#pragma unroll
+					for (int p = 0; p < NPL; p++)
+						smp[par][p][0] = smp[par][p][2], smp[par][p][1] = smp[par][p][3];
 			}
 
 			const int r = v - 3;
@@ -851,7 +867,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, lane, (int)P.sub_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, P.wrap);
 	// segment touches the top / bottom border (or wraps over it): needs the row boundary code
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	// (the unrolled row loop may run up to 5 slots past the segment and prefetches 2 further)
@@ -1040,6 +1056,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 						lpv[k] = 0, hpv[k] = 0;
+				if (HEDGE && lc.he.half)
+					lpv[0] = lpv[1], lpv[2] = lpv[3], hpv[0] = hpv[1], hpv[2] = hpv[3];
 
 				V ev[4], od[4];
 #pragma unroll
@@ -1180,7 +1198,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	if (!id.valid)
 		return;  // U8: units come in pairs and the workgroup is one pair, so both waves leave together
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, lane, (int)P.sub_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, P.wrap);
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
 	if (lc.hedge)

@@ -200,6 +200,56 @@ def test_staged_level0_for_1_2_3_channels(po, path_mode):
                 assert np.array_equal(dec2, od2), ("adversarial", ch, w, h, td, wavelet, wrap, color)
 
 
+def test_level_widths_2_mod_4(po, path_mode):
+    """An odd number of coefficient columns: the last strip of the streaming kernels starts one column early
+    (ako_stream.hip.h: lane_columns).  Widths of 2 mod 4 over one, two and many strips, every wavelet and
+    wrap (REPEAT and single-strip levels stay on the window engine), 4 / 3 / 1 channels, tiles, adversarial
+    streams; in 'auto' mode level 0 of the wide cases must actually have streamed."""
+    nrng = np.random.default_rng(55)
+    cases = [(250, 40, 4, 0), (502, 34, 4, 0), (1366, 36, 4, 0), (742, 130, 3, 0), (990, 30, 1, 0),
+             (1366, 70, 4, 0), (246, 64, 4, 0), (242, 40, 4, 0), (486, 33, 4, 0), (482, 33, 3, 0)]
+    for (w, h, ch, td) in cases:
+        for wavelet in (0, 1, 2):
+            for wrap in range(4):
+                q = int(nrng.choice([0, 16]))
+                img = nrng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+                s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=q // 2, tiles=0)
+                if td:
+                    continue  # (tiles must be powers of two: the tiled case is covered by the odd image sizes above)
+                ob, st = po.encode_image(s, img)
+                assert st == 0
+                body = hip_encode_body(img, s)
+                assert np.array_equal(body, ob[16:]), (w, h, ch, wavelet, wrap, q)
+                od, os_, _ = po.decode_image(ob)
+                dec = hip_decode_body(ob[16:], os_, ch, w, h)
+                assert np.array_equal(dec, od), (w, h, ch, wavelet, wrap, q)
+                junk = nrng.integers(0, 256, ob.size - 16, dtype=np.uint8)
+                dec2 = hip_decode_body(junk, os_, ch, w, h)
+                blob2 = ob.copy()
+                blob2[16:] = junk
+                od2, _, st2 = po.decode_image(blob2)
+                assert st2 == 0 and np.array_equal(dec2, od2), ("adversarial", w, h, ch, wavelet, wrap)
+    # lifting-only planes (PLANES_I16) with such widths, against the oracle's plane lifting
+    for (w, h, wv, wrap) in [(250, 36, 0, 0), (1366, 40, 0, 1), (246, 50, 1, 3), (502, 33, 0, 0)]:
+        plane = po.gen_plane(w * h, seed=w + h).reshape(1, h, w)
+        sp = api.settings(wavelet=wv, wrap=wrap, compression=2, q=0, g=0, color=2)
+        with api.Plan(sp, 1, w, h, batch=1, planes_i16=True) as plan:
+            d = torch.from_numpy(plane.copy()).cuda().reshape(1, 1, h, w)
+            st = plan.encode(d)
+            back = plan.decode(st)
+            plan.synchronize()
+            assert torch.equal(back, d), (w, h, wv, wrap)
+            assert np.array_equal(st.cpu().numpy().reshape(-1), po.lift_plane(wv, wrap, plane[0])), (w, h, wv, wrap)
+    if path_mode == "auto":
+        with api.Plan(api.settings(wavelet=0, wrap=0, compression=2, q=16, g=0), 4, 1366, 70) as plan:
+            plan.set_profiling(True)
+            d_img = torch.from_numpy(nrng.integers(0, 256, (1, 70, 1366, 4), dtype=np.uint8)).cuda()
+            plan.decode(plan.encode(d_img))
+            plan.synchronize()
+            assert plan.kernel_records(False)[0]["name"] == "fwd_stream_dd137_u8"
+            assert plan.kernel_records(True)[-1]["name"].startswith("inv_stream_dd137_u8")
+
+
 def test_adversarial_streams_decode_alike(po, path_mode):
     """Full-range int16 coefficient streams: every int16 wrap-around in the inverse path must agree."""
     rng = random.Random(77)
