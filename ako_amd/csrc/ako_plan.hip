@@ -320,17 +320,18 @@ bool many_planes(const akoHipPlan* pl)
 // streaming kernels need a level width that is a multiple of 4 (no phantom column, and an even
 // number of coefficient columns so that a lane's column pair is never split by the border);
 // in AUTO mode they are used where they pay: wide levels
-// Level widths the streaming kernels take: multiples of 4 (an even number of coefficient columns, no phantom
-// sample), and 2 mod 4 where the last strip can shift by one column (lane_columns() in ako_stream.hip.h):
-// at least two strips, not REPEAT.  Odd widths (phantom last sample) stay on the window engine.
+// Level widths the streaming kernels take (lane_columns() in ako_stream.hip.h).  With an even number of
+// coefficient columns (width = 0 or 3 mod 4) every lane holds a full pair; an odd width adds the phantom
+// last sample, fixed up in the lane of the last pair.  With an odd number of columns (width = 2 or 1
+// mod 4) the last strip shifts by one column: that needs at least two strips, a last strip of three
+// columns or more (with a single one the strip before it would need border values inside its own net
+// range) and a wrap mode that does not pair up columns across the border (REPEAT does).
 bool stream_width_ok(const akoHipPlan* pl, const LevelGeom& L)
 {
-	if ((L.cw & 1) != 0 || L.cw < 8)
+	if (L.cw < 8)
 		return false;
-	if ((L.cw & 3) == 0)
+	if ((L.tw & 1) == 0)
 		return true;
-	// ... and a last strip of three columns or more (tw odd: tw % SNET is 1, 3, 5, ...): with a single
-	// column the strip before it would need border values inside its own net range
 	return L.tw > (uint32_t)SNET && (L.tw % SNET) != 1 && pl->s.wrap != AKO_WRAP_REPEAT;
 }
 

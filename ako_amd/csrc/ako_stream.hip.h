@@ -181,6 +181,7 @@ struct HEdge
 	bool oob_l, oob_r;  // this lane is such a lane
 	bool first, last;   // this lane holds columns 0,1 / T-2,T-1
 	bool half;          // this lane holds column T-1 in its FIRST slot (odd T, strip not shifted): see lane_columns()
+	bool drop_last;     // odd level width: this lane's fourth sample is the phantom one (lifting.c:111-112,140-142)
 	int lane_first, lane_last;
 	int wrap;
 };
@@ -439,6 +440,7 @@ struct LaneCols
 	int cs;   // first of the lane's two coefficient columns, clamped / wrapped likewise
 	HEdge he;
 	bool hedge;
+	bool rot;  // odd level width: the four samples were fetched one sample early (see lane_columns)
 };
 
 // An ODD number of coefficient columns (level width = 2 mod 4) would leave the last column alone in the
@@ -447,7 +449,12 @@ struct LaneCols
 // applies unchanged.  The strip re-computes the last net column of its left neighbour and stores the same
 // values over it.  Needs a left neighbour (two strips at least) and a wrap mode that does not pair up
 // columns across the border (REPEAT does): see stream_width_ok() in ako_plan.hip.
-__device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips, int lane, int Tc, int wrap)
+//
+// An odd level WIDTH W = 2 Tc - 1 has a phantom last sample, O[Tc-1] := E[Tc-1] (wavelet-dd137.c:128-132).  The
+// lane of the last pair (and every lane whose clamped / wrapped pair is the last one) must not read sample W:
+// it fetches samples W-4 .. W-1 instead and the callers rotate them into place (E0 O0 E1 | E1); on the way
+// back the lane stores three samples instead of four.
+__device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips, int lane, int Tc, int W, int wrap)
 {
 	LaneCols lc;
 	const int c_base = (int)strip * SNET - SORG - (((Tc & 1) && strip + 1 == strips) ? 1 : 0);
@@ -466,12 +473,17 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	// slot.  The lane's second slot (column Tc) is never needed: stream_width_ok() only admits widths whose
 	// last strip holds three columns or more, which keeps this strip's net outputs clear of the border.
 	lc.he.half = (lc.c0 == Tc - 1);
-	lc.hedge = lc.he.left || lc.he.right;  // (a half lane only exists where he.right is set)
+	const bool phantom = (W & 1) != 0;
+	lc.he.drop_last = phantom && lc.he.last;
+	// (a half lane only exists where he.right is set; the phantom fix-ups also live in the border variants)
+	lc.hedge = lc.he.left || lc.he.right ||
+	           (phantom && ((c_base + 128 >= Tc) || (wrap == W_REPEAT && c_base < 0)));  // some lane maps to the last pair
 	if (wrap == W_REPEAT)
 		lc.cs = max(map_index(lc.c0, Tc, W_REPEAT) & ~1, 0);  // pairs stay together: c0 and Tc are even
 	else
 		lc.cs = min(max(lc.c0, 0), Tc - 2);
-	lc.xs = 2 * lc.cs;
+	lc.rot = phantom && (lc.cs == Tc - 2);
+	lc.xs = lc.rot ? (W - 4) : (2 * lc.cs);
 	return lc;
 }
 
@@ -813,6 +825,13 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					smp[par][0][2] = zero_row ? (V)0 : (V)lo16(raw.a[par].y);
 					smp[par][0][3] = zero_row ? (V)0 : (V)hi16(raw.a[par].y);
 				}
+				if (HEDGE && lc.rot)  // fetched as samples W-4 .. W-1: move W-3, W-2, W-1 into place, phantom := E1
+#pragma unroll
+					for (int p = 0; p < NPL; p++)
+					{
+						smp[par][p][0] = smp[par][p][1], smp[par][p][1] = smp[par][p][2];
+						smp[par][p][2] = smp[par][p][3];
+					}
 				if (HEDGE && lc.he.half)
 #pragma unroll
 					for (int p = 0; p < NPL; p++)
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	// segment touches the top / bottom border (or wraps over it): needs the row boundary code
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	// (the unrolled row loop may run up to 5 slots past the segment and prefetches 2 further)
@@ -1126,7 +1145,13 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 							px[k] = pixel_u8x4(rr, gg, bb, his1[k]);
 						}
 					}
-					*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
+					if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
+					{
+						uint32_t* o = reinterpret_cast<uint32_t*>(img + (uint64_t)y * out_pitch);
+						o[0] = px[0], o[1] = px[1], o[2] = px[2];
+					}
+					else
+						*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
 				}
 			}
 			else if constexpr (U8)
@@ -1159,7 +1184,13 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
 						        ((uint32_t)sat8((int)v3) << 24);
 					}
-					*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
+					if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
+					{
+						uint32_t* o = reinterpret_cast<uint32_t*>(img + (uint64_t)y * out_pitch);
+						o[0] = px[0], o[1] = px[1], o[2] = px[2];
+					}
+					else
+						*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
 				}
 			}
 			else if (store_row)
@@ -1169,9 +1200,17 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				{
 					const int y = 2 * r + par;
 					if (y < oh)
-						*reinterpret_cast<uint2*>(dst + (uint64_t)y * out_pitch) =
-						    make_uint2(pack2(to_int(out[par][0][0]), to_int(out[par][0][1])),
-						               pack2(to_int(out[par][0][2]), to_int(out[par][0][3])));
+					{
+						int16_t* o = dst + (uint64_t)y * out_pitch;
+						if (HEDGE && lc.he.drop_last)  // odd width: three samples
+						{
+							*reinterpret_cast<uint32_t*>(o) = pack2(to_int(out[par][0][0]), to_int(out[par][0][1]));
+							o[2] = (int16_t)to_int(out[par][0][2]);
+						}
+						else
+							*reinterpret_cast<uint2*>(o) = make_uint2(pack2(to_int(out[par][0][0]), to_int(out[par][0][1])),
+							                                          pack2(to_int(out[par][0][2]), to_int(out[par][0][3])));
+					}
 				}
 			}
 		});
@@ -1198,7 +1237,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	if (!id.valid)
 		return;  // U8: units come in pairs and the workgroup is one pair, so both waves leave together
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
 	if (lc.hedge)

@@ -200,14 +200,18 @@ def test_staged_level0_for_1_2_3_channels(po, path_mode):
                 assert np.array_equal(dec2, od2), ("adversarial", ch, w, h, td, wavelet, wrap, color)
 
 
-def test_level_widths_2_mod_4(po, path_mode):
-    """An odd number of coefficient columns: the last strip of the streaming kernels starts one column early
-    (ako_stream.hip.h: lane_columns).  Widths of 2 mod 4 over one, two and many strips, every wavelet and
-    wrap (REPEAT and single-strip levels stay on the window engine), 4 / 3 / 1 channels, tiles, adversarial
-    streams; in 'auto' mode level 0 of the wide cases must actually have streamed."""
+def test_level_widths_not_multiples_of_4(po, path_mode):
+    """An odd number of coefficient columns (the last strip of the streaming kernels starts one column early)
+    and odd widths (phantom last sample), ako_stream.hip.h: lane_columns.  Widths of 1, 2, 3 mod 4 over one,
+    two and many strips, every wavelet and wrap (what the streaming kernels do not take stays on the window
+    engine), 4 / 3 / 2 / 1 channels, adversarial streams, lifting-only planes; in 'auto' mode level 0 of a
+    wide case must actually have streamed."""
     nrng = np.random.default_rng(55)
     cases = [(250, 40, 4, 0), (502, 34, 4, 0), (1366, 36, 4, 0), (742, 130, 3, 0), (990, 30, 1, 0),
-             (1366, 70, 4, 0), (246, 64, 4, 0), (242, 40, 4, 0), (486, 33, 4, 0), (482, 33, 3, 0)]
+             (1366, 70, 4, 0), (246, 64, 4, 0), (242, 40, 4, 0), (486, 33, 4, 0), (482, 33, 3, 0),
+             # odd widths: phantom last sample, with an even (251, 1367, 487) and an odd (253, 1001, 245) column count
+             (251, 40, 4, 0), (253, 41, 4, 0), (1001, 35, 4, 0), (1367, 37, 4, 0), (487, 64, 3, 0), (245, 33, 1, 0),
+             (241, 33, 4, 0), (1001, 131, 2, 0)]
     for (w, h, ch, td) in cases:
         for wavelet in (0, 1, 2):
             for wrap in range(4):
@@ -230,7 +234,8 @@ def test_level_widths_2_mod_4(po, path_mode):
                 od2, _, st2 = po.decode_image(blob2)
                 assert st2 == 0 and np.array_equal(dec2, od2), ("adversarial", w, h, ch, wavelet, wrap)
     # lifting-only planes (PLANES_I16) with such widths, against the oracle's plane lifting
-    for (w, h, wv, wrap) in [(250, 36, 0, 0), (1366, 40, 0, 1), (246, 50, 1, 3), (502, 33, 0, 0)]:
+    for (w, h, wv, wrap) in [(250, 36, 0, 0), (1366, 40, 0, 1), (246, 50, 1, 3), (502, 33, 0, 0), (251, 36, 0, 0),
+                             (253, 37, 0, 1), (1001, 40, 0, 2), (1367, 33, 1, 3), (487, 50, 2, 0)]:
         plane = po.gen_plane(w * h, seed=w + h).reshape(1, h, w)
         sp = api.settings(wavelet=wv, wrap=wrap, compression=2, q=0, g=0, color=2)
         with api.Plan(sp, 1, w, h, batch=1, planes_i16=True) as plan:
@@ -241,13 +246,42 @@ def test_level_widths_2_mod_4(po, path_mode):
             assert torch.equal(back, d), (w, h, wv, wrap)
             assert np.array_equal(st.cpu().numpy().reshape(-1), po.lift_plane(wv, wrap, plane[0])), (w, h, wv, wrap)
     if path_mode == "auto":
-        with api.Plan(api.settings(wavelet=0, wrap=0, compression=2, q=16, g=0), 4, 1366, 70) as plan:
-            plan.set_profiling(True)
-            d_img = torch.from_numpy(nrng.integers(0, 256, (1, 70, 1366, 4), dtype=np.uint8)).cuda()
-            plan.decode(plan.encode(d_img))
-            plan.synchronize()
-            assert plan.kernel_records(False)[0]["name"] == "fwd_stream_dd137_u8"
-            assert plan.kernel_records(True)[-1]["name"].startswith("inv_stream_dd137_u8")
+        for ww in (1366, 1001, 1367):
+            with api.Plan(api.settings(wavelet=0, wrap=0, compression=2, q=16, g=0), 4, ww, 70) as plan:
+                plan.set_profiling(True)
+                d_img = torch.from_numpy(nrng.integers(0, 256, (1, 70, ww, 4), dtype=np.uint8)).cuda()
+                plan.decode(plan.encode(d_img))
+                plan.synchronize()
+                assert plan.kernel_records(False)[0]["name"] == "fwd_stream_dd137_u8", ww
+                assert plan.kernel_records(True)[-1]["name"].startswith("inv_stream_dd137_u8"), ww
+
+
+def test_border_geometries_of_the_streaming_kernels(po, path_mode):
+    """Every way the right border can fall into the strips: column counts 120 k + r for r around 0 and around
+    a full strip, as even and as odd level widths, all wraps and wavelets.  (auto / stream modes only.)"""
+    if path_mode not in ("auto", "stream"):
+        pytest.skip("covered in the auto and stream modes")
+    nrng = np.random.default_rng(808)
+    widths = []
+    for k in (1, 2, 3):
+        for r in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 117, 118, 119):
+            tc = 120 * k + r
+            widths += [2 * tc, 2 * tc - 1]
+    for w in widths:
+        h = int(nrng.integers(24, 40))
+        ch = int(nrng.choice([4, 4, 3, 1]))
+        wavelet = int(nrng.integers(0, 3))
+        for wrap in range(4):
+            q = int(nrng.choice([0, 12]))
+            img = nrng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+            s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=q // 3)
+            ob, st = po.encode_image(s, img)
+            assert st == 0
+            body = hip_encode_body(img, s)
+            assert np.array_equal(body, ob[16:]), (w, h, ch, wavelet, wrap, q)
+            od, os_, _ = po.decode_image(ob)
+            dec = hip_decode_body(ob[16:], os_, ch, w, h)
+            assert np.array_equal(dec, od), (w, h, ch, wavelet, wrap, q)
 
 
 def test_adversarial_streams_decode_alike(po, path_mode):
