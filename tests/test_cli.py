@@ -194,3 +194,32 @@ def test_cli_tiles_extra_round_trips(tools, tmp_path):
     r = run([os.path.join(tools, "akodec"), "-i", str(ako), "-o", str(back), "-e", "3"])
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(pngutil.read_png(back.read_bytes()), img)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,image,flags", [c for c in CASES if c[0] in ("cfg0_cdf53_q16", "ratio20", "subg_mirror_gate",
+                                                                             "haar_gray", "none_ga")],
+                         ids=lambda v: v if isinstance(v, str) and "_" in v else None)
+def test_reference_tools_run_unchanged_on_this_library(tmp_path, name, image, flags):
+    """INTEGRATION.md, way 1: the REFERENCE'S OWN akoenc / akodec binaries (built into oracle/_ref/ by
+    oracle/Makefile) with this library preloaded in place of theirs -- same files, same printed lines."""
+    ref_enc = os.path.join(ROOT, "oracle", "_ref", "akoenc-ref")
+    ref_dec = os.path.join(ROOT, "oracle", "_ref", "akodec-ref")
+    lib = os.path.join(ROOT, "ako_amd", "libako.so")
+    if not (os.path.exists(ref_enc) and os.path.exists(ref_dec)):
+        pytest.skip("the reference tools were not built (oracle/_ref)")
+    gold = GOLD[name]
+    env = dict(os.environ, LD_PRELOAD=lib)
+    png, ako, back = tmp_path / "in.png", tmp_path / "out.ako", tmp_path / "back.png"
+    png.write_bytes(pngutil.write_png(make_image(image)))
+    r = run([ref_enc, "-i", str(png), "-o", str(ako), "-ch"] + flags, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    blob = ako.read_bytes()
+    assert len(blob) == gold["blob_bytes"] and f"{zlib.adler32(blob) & 0xFFFFFFFF:08x}" == gold["blob_adler32"]
+    assert r.stdout.strip().splitlines()[-1] == gold["encoder_summary"]
+    r = run([ref_dec, "-i", str(ako), "-o", str(back), "-ch"], env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines()[-1] == gold["decoder_summary"]
+    # the preload really took effect: without a usable GPU path this library refuses, the reference's would not
+    r = run([ref_enc, "-i", str(png)], env=dict(env, AKO_HIP_DEVICE="63", AKO_HIP_QUIET="1"))
+    assert r.returncode == 1 and "Ako error" in r.stdout
