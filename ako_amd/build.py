@@ -55,11 +55,11 @@ def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
     for src in C_SOURCES:
         o = os.path.join(OBJ, os.path.basename(src) + ".o")
         if force or _stale(o, [os.path.join(CSRC, src)] + c_deps):
-            _run(["gcc", "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wextra",
+            _run(["gcc", "-O2", "-std=gnu11", "-pthread", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wextra",
                   "-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     if force or _stale(OUT, objs):
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs + ["-lm"])
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs + ["-lm", "-lpthread"])
     return OUT
 
 

@@ -18,9 +18,11 @@
  */
 #include "ako_host.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 static void fire(const struct akoCallbacks* c, size_t tile, size_t total, enum akoEvent e)
 {
@@ -88,6 +90,57 @@ static void plan_release(int slot, akoHipPlan* plan, int healthy)
 		cached_plans[slot] = plan; /* its key was stored by plan_acquire */
 	else
 		akoHipPlanDestroy(plan);
+}
+
+/* ---- tiles of a Kagari blob parsed in parallel -----------------------------------------------
+ * A tile's bit-stream can only be walked sequentially, but tiles are independent (library/encode.c:115-205):
+ * worker threads pull tile numbers and tokenize them into per-tile lists; the caller then merges the lists
+ * in tile order (and reports the first broken tile exactly where the sequential loop would have). */
+struct tile_job
+{
+	const uint8_t* payload; /* NULL: the block chain ran off the input before this tile */
+	uint32_t block;
+	size_t values, out_base;
+	struct akoKagariTokens tok;
+	size_t used;
+};
+struct tile_pool
+{
+	struct tile_job* jobs;
+	size_t count;
+	size_t next; /* atomically incremented */
+};
+
+static void* tile_worker(void* arg)
+{
+	struct tile_pool* pool = arg;
+	for (;;)
+	{
+		const size_t t = __atomic_fetch_add(&pool->next, 1, __ATOMIC_RELAXED);
+		if (t >= pool->count)
+			return NULL;
+		struct tile_job* j = &pool->jobs[t];
+		j->used = (j->payload != NULL) ? akoHostKagariTokenize(j->values, j->block, j->payload, j->out_base, &j->tok) : 0;
+	}
+}
+
+static void tokenize_tiles(struct tile_job* jobs, size_t count)
+{
+	struct tile_pool pool = {jobs, count, 0};
+	long cores = sysconf(_SC_NPROCESSORS_ONLN);
+	size_t workers = (cores > 1) ? (size_t)cores : 1;
+	if (workers > 16)
+		workers = 16;
+	if (workers > count)
+		workers = count;
+	pthread_t th[16];
+	size_t started = 0;
+	for (size_t k = 1; k < workers; k++) /* the calling thread is worker 0 */
+		if (pthread_create(&th[started], NULL, tile_worker, &pool) == 0)
+			started++;
+	tile_worker(&pool);
+	for (size_t k = 0; k < started; k++)
+		pthread_join(th[k], NULL);
 }
 
 static void complain(const char* where)
@@ -333,6 +386,8 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	akoHipPlan* plan = NULL;
 	struct akoKagariTokens tokens;
 	memset(&tokens, 0, sizeof tokens);
+	struct tile_job* jobs = NULL;
+	size_t n_jobs = 0;
 
 	const struct akoCallbacks cb = (c != NULL) ? *c : akoDefaultCallbacks();
 	if (cb.malloc == NULL || cb.realloc == NULL || cb.free == NULL)
@@ -377,6 +432,34 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 			goto failure;
 		}
 		memset(&tokens, 0, sizeof tokens);
+
+		/* several tiles: walk the chain of block sizes, then parse all tiles at once on worker threads */
+		if (tiles > 1)
+		{
+			if ((jobs = calloc(tiles, sizeof *jobs)) == NULL)
+			{
+				status = AKO_NO_ENOUGH_MEMORY;
+				goto failure;
+			}
+			n_jobs = tiles;
+			const uint8_t* walk = cursor;
+			for (size_t t = 0; t < tiles; t++)
+			{
+				size_t off = 0, bytes = 0;
+				akoHipPlanTileInfo(plan, t, NULL, NULL, NULL, NULL, &off, &bytes);
+				uint32_t block = 0;
+				if ((size_t)(end - walk) < 4)
+					break; /* this tile and every later one keep payload == NULL */
+				memcpy(&block, walk, 4);
+				if ((size_t)(end - walk) - 4 < block)
+					break;
+				jobs[t].payload = walk + 4, jobs[t].block = block;
+				jobs[t].values = bytes / 2, jobs[t].out_base = off / 2;
+				walk += (size_t)block + 4;
+			}
+			tokenize_tiles(jobs, tiles);
+		}
+
 		for (size_t t = 0; t < tiles; t++)
 		{
 			size_t off = 0, bytes = 0;
@@ -395,11 +478,32 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 				status = AKO_BROKEN_INPUT;
 				goto failure;
 			}
-			const size_t used = akoHostKagariTokenize(bytes / 2, block, cursor + 4, off / 2, &tokens);
-			if (used == 0 || used != block) /* compression.c:69-70 */
+			if (jobs != NULL)
 			{
-				status = AKO_BROKEN_INPUT;
-				goto failure;
+				/* merge this tile's list: literals are appended, 'after' counts become global */
+				struct tile_job* j = &jobs[t];
+				if (j->used == 0 || j->used != block) /* compression.c:69-70 */
+				{
+					status = AKO_BROKEN_INPUT;
+					goto failure;
+				}
+				const size_t base = tokens.n_literals;
+				if (base + j->tok.n_literals > 0xFFFFFFF0ull ||
+				    !akoHostKagariTokensAppend(&tokens, &j->tok, (uint32_t)base))
+				{
+					status = AKO_NO_ENOUGH_MEMORY;
+					goto failure;
+				}
+				akoHostKagariTokensFree(&j->tok);
+			}
+			else
+			{
+				const size_t used = akoHostKagariTokenize(bytes / 2, block, cursor + 4, off / 2, &tokens);
+				if (used == 0 || used != block) /* compression.c:69-70 */
+				{
+					status = AKO_BROKEN_INPUT;
+					goto failure;
+				}
 			}
 			cursor += (size_t)block + 4;
 			if (t + 1 == tiles)
@@ -433,6 +537,8 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 			fire(&cb, t, tiles, AKO_EVENT_FORMAT_END);
 		}
 		akoHostKagariTokensFree(&tokens);
+		free(jobs); /* every per-tile list was released when it was merged */
+		jobs = NULL;
 		goto decoded;
 	}
 
@@ -522,6 +628,12 @@ decoded:
 
 failure:
 	akoHostKagariTokensFree(&tokens);
+	if (jobs != NULL)
+	{
+		for (size_t t = 0; t < n_jobs; t++)
+			akoHostKagariTokensFree(&jobs[t].tok);
+		free(jobs);
+	}
 	plan_release(1, plan, 0);
 	if (cb.free != NULL)
 	{

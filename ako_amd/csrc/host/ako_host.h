@@ -47,6 +47,8 @@ struct akoKagariTokens
 };
 AKO_API size_t akoHostKagariTokenize(size_t values_no, size_t input_bytes, const void* input, uint64_t out_base,
                                      struct akoKagariTokens* tok);
+AKO_API int akoHostKagariTokensAppend(struct akoKagariTokens* dst, const struct akoKagariTokens* src,
+                                      uint32_t literal_base);
 AKO_API void akoHostKagariTokensFree(struct akoKagariTokens* tok);
 
 #endif

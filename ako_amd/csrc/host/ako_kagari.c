@@ -313,6 +313,24 @@ size_t akoHostKagariTokenize(size_t values_no, size_t input_bytes, const void* i
 	return source_used(&s);
 }
 
+/* dst += src, with src's literal counts shifted by 'literal_base' (= dst->n_literals before the call) */
+int akoHostKagariTokensAppend(struct akoKagariTokens* dst, const struct akoKagariTokens* src, uint32_t literal_base)
+{
+	if (!tokens_reserve(dst, src->n_literals, src->n_runs))
+		return 0;
+	if (src->n_literals)
+		memcpy(dst->literals + dst->n_literals, src->literals, src->n_literals * sizeof(int16_t));
+	for (size_t k = 0; k < src->n_runs; k++)
+	{
+		struct akoKagariRun r = src->runs[k];
+		r.after += literal_base;
+		dst->runs[dst->n_runs + k] = r;
+	}
+	dst->n_literals += src->n_literals;
+	dst->n_runs += src->n_runs;
+	return 1;
+}
+
 void akoHostKagariTokensFree(struct akoKagariTokens* tok)
 {
 	free(tok->literals);
