@@ -13,7 +13,31 @@
  * points fail with AKO_ERROR.
  *
  * The device-level C-ABI underneath (plans, device-resident encode / decode,
- * lifting-only entry points) is declared in ako_hip.h.
+ * lifting-only entry points, the device entropy stage) is declared in ako_hip.h.
+ *
+ * Typical use (error handling elided):
+ *
+ *     struct akoSettings s = akoDefaultSettings();          // DD13/7, YCoCg, CLAMP, Kagari, q = 16
+ *     s.quantization = 0;                                   // lossless
+ *     void* blob = NULL;
+ *     enum akoStatus st;
+ *     size_t n = akoEncodeExt(NULL, &s, 4, w, h, rgba, &blob, &st);   // NULL callbacks = libc allocator
+ *     ...
+ *     size_t ch, dw, dh;
+ *     uint8_t* pixels = akoDecodeExt(NULL, n, blob, &s, &ch, &dw, &dh, &st);
+ *     akoDefaultFree(pixels);
+ *     akoDefaultFree(blob);
+ *
+ * What happens where: the pixels go to the GPU once; colour transform, lifting, gate / quantization,
+ * stream packing AND the Kagari entropy coder run there; only the compressed body comes back and is
+ * placed behind the 16 byte head (decoder: the host parses the bit-streams -- tiles in parallel --
+ * and the GPU expands the runs, inverts the transform and returns the pixels).  Process-wide knobs
+ * are environment variables, listed in INTEGRATION.md: AKO_HIP_DEVICE, AKO_HIP_QUIET,
+ * AKO_HIP_KAGARI, AKO_HIP_PLAN_CACHE, ...
+ *
+ * Thread safety: like the reference, the two entry points are re-entrant and keep no shared state
+ * (each thread caches the device plan of its own previous call); the event callback runs on the
+ * calling thread, per tile, in tile order.
  */
 #ifndef AKO_H
 #define AKO_H
