@@ -7,9 +7,9 @@
 // bit-stream of a tile therefore is a concatenation of per-RUN bit strings whose lengths depend only on
 // (value, run length): data parallel once the runs are known.
 //
-//   1. k_kg_count     flag run starts (value differs from its predecessor, or first of a tile), count / block
+//   1. k_kg_starts<0> flag run starts (value differs from its predecessor, or first of a tile), count / block
 //   2. k_kg_scan      one workgroup: exclusive scan of the block counts -> first run index of every block
-//   3. k_kg_emit      write the start position of every run (compacted, in order)
+//   3. k_kg_starts<1> write the start position of every run (compacted, in order)
 //   4. k_kg_bits      bits of every run; per-block sums
 //   5. k_kg_scan      scan of the block sums -> bit offset of every block of runs
 //   6. k_kg_tiles     one wave per tile: bit offset of the tile's first run; k_kg_layout: sizes, the
@@ -94,65 +94,101 @@ __device__ __forceinline__ uint64_t kg_run_bits(uint32_t cb, uint64_t len)
 
 // ---- 1 / 3: run starts ---------------------------------------------------------------------------
 
-// value index handled by (thread, j) inside a chunk: consecutive threads read consecutive values
+// value index handled by (thread, j) inside a chunk of the EXPAND kernel: consecutive threads, consecutive values
 __device__ __forceinline__ uint32_t kg_slot(int j)
 {
 	return (uint32_t)j * KG_THREADS + threadIdx.x;
 }
 
+constexpr int KG_RUN_VALUES = 32;                          // consecutive values per thread in k_kg_starts
+constexpr int KG_RUN_CHUNK = KG_THREADS * KG_RUN_VALUES;   // values per workgroup there (= KgTile::first_block unit)
+
+// Every thread takes 32 consecutive values (four 16-byte loads; tile streams are only 2-byte aligned, which the
+// global path tolerates) plus the one in front of them, and marks the values that differ from their
+// predecessor.  Threads are in value order, so the rank of a run start is the exclusive scan of the per-thread
+// counts plus the number of set bits below it.
 template <bool EMIT>
 __global__ __launch_bounds__(KG_THREADS) void k_kg_starts(const int16_t* __restrict__ stream, const KgTile* __restrict__ tiles,
                                                           uint32_t n_tiles, uint32_t* __restrict__ block_count,
                                                           const uint32_t* __restrict__ block_first_run,
                                                           uint32_t* __restrict__ run_start)
 {
-	__shared__ uint32_t part[KG_PER_THREAD * (KG_THREADS / 64) + 1];
+	__shared__ uint32_t wave_total[KG_THREADS / 64];
 	const uint32_t b = blockIdx.x;
 	const uint32_t t = kg_upper(n_tiles, b, [&](uint32_t k) { return (uint64_t)tiles[k].first_block; });
 	const KgTile tile = tiles[t];
-	const uint64_t base = (uint64_t)(b - tile.first_block) * KG_CHUNK;
+	const uint64_t i0 = (uint64_t)(b - tile.first_block) * KG_RUN_CHUNK + (uint64_t)threadIdx.x * KG_RUN_VALUES;
 	const int16_t* s = stream + tile.off;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-	uint64_t ballots[KG_PER_THREAD];
-#pragma unroll
-	for (int j = 0; j < KG_PER_THREAD; j++)
+	uint32_t mask = 0;
+	if (i0 < tile.n)
 	{
-		const uint64_t i = base + kg_slot(j);
-		bool start = false;
-		if (i < tile.n)
-			start = (i == 0) || (s[i] != s[i - 1]);
-		ballots[j] = __ballot(start);
-		if (lane == 0)
-			part[j * (KG_THREADS / 64) + wave] = (uint32_t)__popcll(ballots[j]);
-	}
-	__syncthreads();
-	if (threadIdx.x == 0)  // 32 partial counts, in value order (j major, wave minor)
-	{
-		uint32_t run = 0;
-		for (int k = 0; k < KG_PER_THREAD * (KG_THREADS / 64); k++)
+		int16_t v[KG_RUN_VALUES];
+		const uint32_t have = (tile.n - i0 < KG_RUN_VALUES) ? (uint32_t)(tile.n - i0) : KG_RUN_VALUES;
+		if (have == KG_RUN_VALUES)
 		{
-			const uint32_t c = part[k];
-			part[k] = run;
-			run += c;
+#pragma unroll
+			for (int q = 0; q < KG_RUN_VALUES / 8; q++)
+			{
+				const uint4 u = *reinterpret_cast<const uint4*>(s + i0 + 8 * q);
+				const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					v[8 * q + 2 * j] = (int16_t)(w[j] & 0xFFFFu), v[8 * q + 2 * j + 1] = (int16_t)(w[j] >> 16);
+			}
 		}
-		part[KG_PER_THREAD * (KG_THREADS / 64)] = run;
+		else
+		{
+#pragma unroll
+			for (int j = 0; j < KG_RUN_VALUES; j++)
+				v[j] = ((uint32_t)j < have) ? s[i0 + j] : (int16_t)0;
+		}
+		int16_t prev = (i0 == 0) ? (int16_t)0 : s[i0 - 1];
+#pragma unroll
+		for (int j = 0; j < KG_RUN_VALUES; j++)
+		{
+			const bool start = ((uint32_t)j < have) && ((i0 + j == 0) || (v[j] != prev));
+			mask |= (start ? 1u : 0u) << j;
+			prev = v[j];
+		}
 	}
+	const uint32_t mine = (uint32_t)__popc(mask);
+
+	// exclusive scan of 'mine' over the workgroup: inside the wave by shuffles, across the four waves through LDS
+	uint32_t incl = mine;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1)
+	{
+		const uint32_t up = __shfl_up(incl, d, 64);
+		if (lane >= d)
+			incl += up;
+	}
+	if (lane == 63)
+		wave_total[wave] = incl;
 	__syncthreads();
+	uint32_t before = 0, total = 0;
+#pragma unroll
+	for (int k = 0; k < KG_THREADS / 64; k++)
+	{
+		if (k < wave)
+			before += wave_total[k];
+		total += wave_total[k];
+	}
 	if (!EMIT)
 	{
 		if (threadIdx.x == 0)
-			block_count[b] = part[KG_PER_THREAD * (KG_THREADS / 64)];
+			block_count[b] = total;
 		return;
 	}
-	const uint32_t first = block_first_run[b];
-#pragma unroll
-	for (int j = 0; j < KG_PER_THREAD; j++)
-		if ((ballots[j] >> lane) & 1)
-		{
-			const uint32_t rank = part[j * (KG_THREADS / 64) + wave] + (uint32_t)__popcll(ballots[j] & ((1ull << lane) - 1));
-			run_start[first + rank] = (uint32_t)(tile.off + base + kg_slot(j));
-		}
+	uint32_t rank = block_first_run[b] + before + incl - mine;
+	const uint32_t at = (uint32_t)(tile.off + i0);
+	while (mask)
+	{
+		const int j = __ffs(mask) - 1;
+		mask &= mask - 1;
+		run_start[rank++] = at + (uint32_t)j;
+	}
 }
 
 // ---- 2 / 5: exclusive scan by ONE workgroup (n up to a few million) --------------------------------

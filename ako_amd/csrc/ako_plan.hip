@@ -1246,7 +1246,7 @@ static int kagari_state(akoHipPlan* pl)
 		expect += ti.stream_bytes;
 		tiles[t].off = ti.stream_off / 2, tiles[t].n = ti.stream_bytes / 2;
 		tiles[t].first_block = (uint32_t)blocks, tiles[t].pad = 0;
-		blocks += (tiles[t].n + KG_CHUNK - 1) / KG_CHUNK;
+		blocks += (tiles[t].n + KG_RUN_CHUNK - 1) / KG_RUN_CHUNK;
 		stage[t] = ((ti.stream_off + 7) & ~(uint64_t)7) + 16 * t;  // 8-byte aligned, 8+ bytes of slack each
 	}
 	k->n_tiles = (uint32_t)tiles.size(), k->n_blocks = (uint32_t)blocks;
