@@ -288,6 +288,8 @@ class Plan:
             self._p = None
 
     def __del__(self):
+        if lib is None:  # interpreter shutdown: module globals are gone, the process takes the plan with it
+            return
         self.close()
 
     def __enter__(self):
