@@ -141,6 +141,7 @@ struct akoHipPlan
 	};
 	std::vector<Pending> pending[2];
 	KagariState* kg = nullptr;
+	bool owns_stream = false;
 };
 
 namespace
@@ -960,6 +961,12 @@ akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, siz
 		pl = new akoHipPlan();
 		pl->device = device;
 		pl->stream = (hipStream_t)hip_stream;
+		if (hip_stream == nullptr && (flags & AKO_HIP_PLAN_OWN_STREAM))
+		{
+			if (hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking) != hipSuccess)
+				PLAN_FAIL(AKO_ERROR, "hipStreamCreate failed");
+			pl->owns_stream = true;
+		}
 		pl->s = *settings;
 		pl->channels = channels, pl->w = image_w, pl->h = image_h, pl->batch = batch, pl->flags = flags;
 		if (flags & AKO_HIP_PLAN_PLANES_I16)
@@ -1063,6 +1070,11 @@ void akoHipPlanDestroy(akoHipPlan* pl)
 			(void)hipEventDestroy(e.a);
 			(void)hipEventDestroy(e.b);
 		}
+	if (pl->owns_stream)
+	{
+		(void)hipStreamSynchronize(pl->stream);
+		(void)hipStreamDestroy(pl->stream);
+	}
 	delete pl;
 }
 

@@ -79,7 +79,9 @@ static akoHipPlan* plan_acquire(int slot, const struct akoSettings* st, size_t c
 		akoHipPlanDestroy(p);
 	}
 	cached_keys[slot] = key;
-	return akoHipPlanCreate(key.device, st, channels, w, h, 1, NULL, 0, status);
+	/* an own stream per plan: calls from different host threads overlap on the GPU instead of queueing up on
+	 * the legacy default stream (every driver call below ends with a synchronisation of that stream) */
+	return akoHipPlanCreate(key.device, st, channels, w, h, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, status);
 }
 
 static void plan_release(int slot, akoHipPlan* plan, int healthy)

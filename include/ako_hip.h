@@ -48,6 +48,9 @@ const char* akoHipLastError(void);
  */
 #define AKO_HIP_PLAN_PLANES_I16 1u /* lifting-only mode: "images" are int16 planes (channels planes of w x h), no \
                                       colour transform, no saturation; decode writes int16 planes back */
+#define AKO_HIP_PLAN_OWN_STREAM 2u /* with hip_stream == NULL: the plan creates (and owns) a non-blocking stream \
+                                      instead of using the legacy default stream, so that plans of different host \
+                                      threads run side by side; akoHipSynchronize() waits for it */
 
 akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, size_t channels, size_t image_w,
                              size_t image_h, size_t batch, void* hip_stream, unsigned flags,
