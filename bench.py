@@ -336,6 +336,24 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = cpu_baseline(args.workload)
+            if not planes and args.workload in ("full8192", "batch4k", "rgb8192"):
+                # informative, never `value`: the public entry points from pageable host memory, PCIe and the
+                # entropy stage included (pixels -> .ako blob -> pixels of one image)
+                import time
+
+                one = np.ascontiguousarray(host[0])
+                s_k = api.settings(wavelet=api.DD137, wrap=api.CLAMP, compression=api.KAGARI, q=16, g=16)
+                blob = api.encode(one, s_k)  # sets the per-thread plan up
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    blob = api.encode(one, s_k)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    back_px, _ = api.decode(blob)
+                t2 = time.perf_counter()
+                out["host_to_blob"] = {"akoEncodeExt_ms": round((t1 - t0) / 3 * 1e3, 2), "akoDecodeExt_ms": round((t2 - t1) / 3 * 1e3, 2),
+                                       "blob_bytes": int(blob.size), "image": f"{one.shape[1]}x{one.shape[0]}x{one.shape[2]}",
+                                       "note": "pageable host memory, PCIe + device Kagari included; not part of `value`"}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
