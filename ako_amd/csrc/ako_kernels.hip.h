@@ -97,7 +97,7 @@ struct LevelParams
 	uint64_t grp_off[MAX_CH];  // int16 offset of plane p's [head C B D] group of this level
 	int32_t q_luma, g_luma, q_chroma, g_chroma;
 	float rq_luma, rq_chroma;  // (1/q) * (1 + 1e-6): see quantize()
-	uint32_t dbg;              // timing experiments only (AKO_HIP_DBG), 0 in production
+	uint32_t dbg;              // AKO_HIP_DBG: bit 2 switches the XCD-aware workgroup order of the streaming kernels off
 	int32_t* ovf_flag;         // optimistic-float inverse: set when a value may have left int16 (see ako_stream.hip.h)
 };
 

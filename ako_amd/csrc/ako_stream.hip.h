@@ -56,7 +56,6 @@ constexpr int SORG = 4;    // lane 0 holds coefficient columns strip * SNET - SO
 constexpr int SWAVES = THREADS / 64;
 
 // lane i <- lane i-1 / lane i+1 over the whole wave64 (gfx9 DPP wave shifts)
-#ifndef AKO_EXPERIMENT_NO_DPP
 __device__ __forceinline__ int from_prev_lane(int x)
 {
 	return __builtin_amdgcn_mov_dpp(x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
@@ -65,16 +64,6 @@ __device__ __forceinline__ int from_next_lane(int x)
 {
 	return __builtin_amdgcn_mov_dpp(x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
-#else  // timing experiment only: wrong results
-__device__ __forceinline__ int from_prev_lane(int x)
-{
-	return x + 1;
-}
-__device__ __forceinline__ int from_next_lane(int x)
-{
-	return x - 1;
-}
-#endif
 
 __device__ __forceinline__ float from_prev_lane(float x)
 {
@@ -766,15 +755,10 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		for (int par = 0; par < 2; par++)
 		{
 			const int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
-#ifdef AKO_EXPERIMENT_NO_LOADS  // timing experiment only: wrong results
-			if (y == 12345678)
-#endif
-			{
-				if (U8)
-					raw.a[par] = *reinterpret_cast<const RawVec*>(img + (uint64_t)y * row_pitch);
-				else
-					raw.a[par] = *reinterpret_cast<const RawVec*>(src + (uint64_t)y * row_pitch);
-			}
+			if (U8)
+				raw.a[par] = *reinterpret_cast<const RawVec*>(img + (uint64_t)y * row_pitch);
+			else
+				raw.a[par] = *reinterpret_cast<const RawVec*>(src + (uint64_t)y * row_pitch);
 		}
 	};
 
