@@ -284,6 +284,67 @@ def test_border_geometries_of_the_streaming_kernels(po, path_mode):
             assert np.array_equal(dec, od), (w, h, ch, wavelet, wrap, q)
 
 
+def test_optimistic_inverse_around_its_proof_bound(po):
+    """The optimistic fp32 inverse may only keep its result when no int16 wrap could have happened (input
+    magnitudes <= 3560, lifted magnitudes <= 10921, ako_stream.hip.h).  Streams whose coefficients sit just
+    below, at and above those bounds -- random signs, constant blocks and the alternating patterns that drive
+    the lifting sums to their extremes -- must decode exactly like the oracle's wrapping arithmetic."""
+    nrng = np.random.default_rng(4242)
+    w, h, ch = 256, 96, 4
+    for wavelet in (0, 1, 2):
+        for color in (0, 1, 2, 3):
+            s = po.settings(wavelet=wavelet, color=color, wrap=0, compression=2, q=0, g=0)
+            ob, st = po.encode_image(s, nrng.integers(0, 256, (h, w, ch), dtype=np.uint8))
+            assert st == 0
+            n = (ob.size - 16) // 2
+            xs = np.arange(n)
+            # positions of the lift heads (the quantization step each [C][B][D] group was written with, SURVEY
+            # A.4): they stay as the encoder wrote them (1), otherwise they would de-quantize everything
+            dims, cw, chh = [], w, h
+            while cw > 2 and chh > 2:
+                cw, chh = (cw + 1) // 2, (chh + 1) // 2
+                dims.append((cw, chh))
+            heads, at = [], cw * chh * ch
+            for (tw, th) in reversed(dims):
+                for _ in range(ch):
+                    heads.append(at)
+                    at += 1 + 3 * tw * th
+            assert at == n
+            original = ob[16:].view(np.int16)
+            assert all(int(original[p]) in (0, 1) for p in heads)
+            for bound in (1200, 3000, 3500, 3560, 3561, 3700, 5000, 10900, 10922, 16000):
+                for pattern in range(5):
+                    if pattern == 0:
+                        v = nrng.integers(-bound, bound + 1, n)
+                    elif pattern == 1:
+                        v = np.where(nrng.random(n) < 0.5, bound, -bound)
+                    elif pattern == 2:
+                        v = np.where(xs % 2 == 0, bound, -bound)              # alternating along the stream
+                    elif pattern == 3:
+                        v = np.where((xs // 2) % 2 == 0, bound, -bound)
+                    else:
+                        v = np.full(n, bound)
+                        v[nrng.integers(0, n, n // 50)] = -bound
+                    v = v.astype(np.int16)
+                    # three framings: the pattern everywhere (the low levels then blow the level-0 low-pass up:
+                    # fallback territory), only in the level-0 high-pass groups over a zero low-pass, and the same
+                    # over a flat low-pass of the same magnitude (the input bound met from both sides)
+                    level0 = heads[-ch]
+                    for framing in range(3):
+                        u = v.copy()
+                        if framing >= 1:
+                            u[:level0] = 0
+                        if framing == 2:
+                            u[:cw * chh * ch] = bound  # the final low-pass planes: a DC of 'bound' reaches level 0
+                        u[heads] = original[heads]
+                        blob = ob.copy()
+                        blob[16:] = u.view(np.uint8)
+                        want, s_dec, st2 = po.decode_image(blob)
+                        assert st2 == 0
+                        got = hip_decode_body(blob[16:], s_dec, ch, w, h)
+                        assert np.array_equal(got, want), (wavelet, color, bound, pattern, framing)
+
+
 def test_adversarial_streams_decode_alike(po, path_mode):
     """Full-range int16 coefficient streams: every int16 wrap-around in the inverse path must agree."""
     rng = random.Random(77)
