@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="full8192", choices=["full8192", "batch4k", "lift4096", "tiles16k", "rgb8192"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="steps in flight: consecutive steps alternate over this many HIP streams / buffer sets")
     return ap.parse_args()
 
