@@ -363,6 +363,11 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit, bool
 {
 	StreamGeom G;
 	G.strips = (L.tw + SNET - 1) / SNET;
+	G.wide = 0;
+	// 121..128 coefficient columns (an even number): one strip without halo lanes instead of two
+	const char* wide_env = getenv("AKO_HIP_WIDE");
+	if (L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && !(wide_env != nullptr && atoi(wide_env) == 0))
+		G.strips = 1, G.wide = 1;
 	uint32_t seg_rows = 0;
 	if (const char* e = getenv("AKO_HIP_SEG_ROWS"))
 		seg_rows = (uint32_t)atoi(e);

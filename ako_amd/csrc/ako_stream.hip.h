@@ -171,6 +171,8 @@ struct HEdge
 	bool first, last;   // this lane holds columns 0,1 / T-2,T-1
 	bool half;          // this lane holds column T-1 in its FIRST slot (odd T, strip not shifted): see lane_columns()
 	bool drop_last;     // odd level width: this lane's fourth sample is the phantom one (lifting.c:111-112,140-142)
+	bool nh_left, nh_right;  // "wide" strips: the border sits at lane 0 / lane 63, there are no out-of-range lanes on
+	                         // that side to hold the border values (see edge_taps)
 	int lane_first, lane_last;
 	int wrap;
 };
@@ -194,6 +196,32 @@ __device__ __forceinline__ void fix_halo_lanes(V& a0, V& a1, const HEdge& ed)
 	}
 }
 
+// Wide strips (a tile of 121..128 coefficient columns in ONE wave, no halo lanes): what the neighbour
+// shifts deliver at the two border lanes is replaced by the border values of the sequence (a0 = column c0,
+// a1 = column c1): prev1 / prev2 = columns c0-1 / c0-2 as seen by the FIRST lane, next1 / next2 = columns
+// c1+1 / c1+2 as seen by the LAST lane.  CLAMP and MIRROR take the nearest in-range value (MIRROR's far
+// taps are substituted by the callers as everywhere else), ZERO takes 0, REPEAT the other end.
+template <typename V>
+struct BorderVals
+{
+	V prev1, prev2, next1, next2;
+};
+template <typename V>
+__device__ __forceinline__ BorderVals<V> border_values(V a0, V a1, const HEdge& ed)
+{
+	BorderVals<V> b;
+	if (ed.wrap == W_ZERO)
+		b.prev1 = b.prev2 = b.next1 = b.next2 = (V)0;
+	else if (ed.wrap == W_REPEAT)
+	{
+		b.prev1 = read_lane(a1, ed.lane_last), b.prev2 = read_lane(a0, ed.lane_last);
+		b.next1 = read_lane(a0, ed.lane_first), b.next2 = read_lane(a1, ed.lane_first);
+	}
+	else
+		b.prev1 = b.prev2 = a0, b.next1 = b.next2 = a1;  // only read in the first / last lane, where they are the border columns
+	return b;
+}
+
 // Horizontal forward lift of one row: samples (E0 O0 E1 O1) of this lane's two coefficient
 // columns -> (L0 L1 H0 H1).  Valid in lanes 2..61.
 template <int KIND, bool NARROW, bool HEDGE, typename V>
@@ -208,10 +236,18 @@ __device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdg
 	if (HEDGE)
 		fix_halo_lanes(E0, E1, ed);
 
-	const V eR0 = from_next_lane(E0);
+	V eR0 = from_next_lane(E0);
 	V eL = 0, eR1 = 0;
 	if (KIND == K_DD137)
 		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	if (HEDGE && (ed.nh_left || ed.nh_right))
+	{
+		const BorderVals<V> b = border_values(E0, E1, ed);
+		if (ed.nh_left && ed.first)
+			eL = b.prev1;
+		if (ed.nh_right && ed.last)
+			eR0 = b.next1, eR1 = b.next2;
+	}
 	V p2_0 = eR0, p2_1 = eR1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.last)
 		p2_0 = eL, p2_1 = E0;  // far tap := opposite near tap
@@ -221,10 +257,18 @@ __device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdg
 	if (HEDGE)
 		fix_halo_lanes(H0, H1, ed);
 
-	const V hL1 = from_prev_lane(H1);
+	V hL1 = from_prev_lane(H1);
 	V hL0 = 0, hR0 = 0;
 	if (KIND == K_DD137)
 		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	if (HEDGE && (ed.nh_left || ed.nh_right))
+	{
+		const BorderVals<V> b = border_values(H0, H1, ed);
+		if (ed.nh_left && ed.first)
+			hL1 = b.prev1, hL0 = b.prev2;
+		if (ed.nh_right && ed.last)
+			hR0 = b.next1;
+	}
 	V l2_0 = hL0, l2_1 = hL1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.first)
 		l2_0 = H1, l2_1 = hR0;
@@ -246,10 +290,18 @@ __device__ __forceinline__ void hlift_inverse(V L0, V L1, V H0, V H1, const HEdg
 	if (HEDGE)
 		fix_halo_lanes(H0, H1, ed);
 
-	const V hL1 = from_prev_lane(H1);
+	V hL1 = from_prev_lane(H1);
 	V hL0 = 0, hR0 = 0;
 	if (KIND == K_DD137)
 		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	if (HEDGE && (ed.nh_left || ed.nh_right))
+	{
+		const BorderVals<V> b = border_values(H0, H1, ed);
+		if (ed.nh_left && ed.first)
+			hL1 = b.prev1, hL0 = b.prev2;
+		if (ed.nh_right && ed.last)
+			hR0 = b.next1;
+	}
 	V l2_0 = hL0, l2_1 = hL1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.first)
 		l2_0 = H1, l2_1 = hR0;
@@ -259,10 +311,18 @@ __device__ __forceinline__ void hlift_inverse(V L0, V L1, V H0, V H1, const HEdg
 	if (HEDGE)
 		fix_halo_lanes(E0, E1, ed);
 
-	const V eR0 = from_next_lane(E0);
+	V eR0 = from_next_lane(E0);
 	V eL = 0, eR1 = 0;
 	if (KIND == K_DD137)
 		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	if (HEDGE && (ed.nh_left || ed.nh_right))
+	{
+		const BorderVals<V> b = border_values(E0, E1, ed);
+		if (ed.nh_left && ed.first)
+			eL = b.prev1;
+		if (ed.nh_right && ed.last)
+			eR0 = b.next1, eR1 = b.next2;
+	}
 	V p2_0 = eR0, p2_1 = eR1;
 	if (HEDGE && KIND == K_DD137 && ed.wrap == W_MIRROR && ed.last)
 		p2_0 = eL, p2_1 = E0;
@@ -358,6 +418,7 @@ __device__ __forceinline__ void vstep_inverse(VInv<V>& s, V LP, V HP, int v, int
 struct StreamGeom
 {
 	uint32_t strips, segs, seg_rows;
+	uint32_t wide;  // one strip without halo lanes covers the whole tile width (121..128 coefficient columns)
 };
 
 // unit -> (strip, segment, plane group, tile instance)
@@ -430,6 +491,7 @@ struct LaneCols
 	HEdge he;
 	bool hedge;
 	bool rot;  // odd level width: the four samples were fetched one sample early (see lane_columns)
+	bool net;  // this lane's columns belong to the strip's net range (it stores them)
 };
 
 // An ODD number of coefficient columns (level width = 2 mod 4) would leave the last column alone in the
@@ -443,17 +505,27 @@ struct LaneCols
 // lane of the last pair (and every lane whose clamped / wrapped pair is the last one) must not read sample W:
 // it fetches samples W-4 .. W-1 instead and the callers rotate them into place (E0 O0 E1 | E1); on the way
 // back the lane stores three samples instead of four.
-__device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips, int lane, int Tc, int W, int wrap)
+//
+// A tile of 121..128 coefficient columns would need a second strip for a handful of columns.  Both its borders
+// are tile borders, where nothing real lies beyond: the WIDE strip starts at column 0 in lane 0, stores from
+// all its in-range lanes, and takes the taps across the borders from border_values() instead of from
+// out-of-range lanes (right side: only when the 128 columns leave no lane over).
+__device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips, bool wide, int lane, int Tc, int W, int wrap)
 {
 	LaneCols lc;
-	const int c_base = (int)strip * SNET - SORG - (((Tc & 1) && strip + 1 == strips) ? 1 : 0);
+	const int c_base = wide ? 0 : ((int)strip * SNET - SORG - (((Tc & 1) && strip + 1 == strips) ? 1 : 0));
 	lc.c0 = c_base + 2 * lane;
+	lc.net = wide || ((lane >= 2) && (lane < 62));
 	lc.he.wrap = wrap;
 	lc.he.left = (wrap != W_REPEAT) && (c_base < 0);
 	lc.he.right = (wrap != W_REPEAT) && (c_base + 128 > Tc);
+	lc.he.nh_left = wide;
+	// (REPEAT needs real values from the other end, and a single out-of-range lane could not compute them:
+	// its own far taps would lie beyond the wave)
+	lc.he.nh_right = wide && (Tc == 128 || wrap == W_REPEAT);
 	lc.he.oob_l = lc.c0 < 0;
 	lc.he.oob_r = lc.c0 >= Tc;
-	lc.he.lane_first = SORG / 2;
+	lc.he.lane_first = wide ? 0 : SORG / 2;
 	lc.he.lane_last = (Tc - 2 - c_base) / 2;
 	lc.he.first = (lc.c0 == 0);
 	lc.he.last = (lc.c0 == Tc - 2);
@@ -465,7 +537,7 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	const bool phantom = (W & 1) != 0;
 	lc.he.drop_last = phantom && lc.he.last;
 	// (a half lane only exists where he.right is set; the phantom fix-ups also live in the border variants)
-	lc.hedge = lc.he.left || lc.he.right ||
+	lc.hedge = wide || lc.he.left || lc.he.right ||
 	           (phantom && ((c_base + 128 >= Tc) || (wrap == W_REPEAT && c_base < 0)));  // some lane maps to the last pair
 	if (wrap == W_REPEAT)
 		lc.cs = max(map_index(lc.c0, Tc, W_REPEAT) & ~1, 0);  // pairs stay together: c0 and Tc are even
@@ -710,7 +782,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	// a slot's pixels no longer covers the stores of the previous slot (stores count in vmcnt on gfx950).
 	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
 	const uint64_t nsub = (uint64_t)Tc * Tr;
-	const bool store_lane = (lane >= 2) && (lane < 62) && (c0 >= 0) && (c0 < Tc);
+	const bool store_lane = lc.net && (c0 >= 0) && (c0 < Tc);
 	constexpr uint32_t OOB = 0xFFFFFFFFu;
 	constexpr int RSRC_FLAGS = 0x00020000;  // gfx9 raw buffer, 32 bit data format
 	const uint64_t stream_left = (P.stream_stride - td.stream_off) * 2;  // bytes up to the end of the image's stream
@@ -870,7 +942,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	// segment touches the top / bottom border (or wraps over it): needs the row boundary code
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	// (the unrolled row loop may run up to 5 slots past the segment and prefetches 2 further)
@@ -976,7 +1048,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 		out_pitch = P.dst_pitch;
 	}
 	// the output width is 2 * Tc here (level widths that are multiples of 4), rows may be odd in number
-	const bool store_lane = (lane >= 2) && (lane < 62) && (c0 >= 0) && (c0 < Tc);
+	const bool store_lane = lc.net && (c0 >= 0) && (c0 < Tc);
 	(void)ow;
 
 	VInv<V> st[NPL][4];
@@ -1221,7 +1293,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	if (!id.valid)
 		return;  // U8: units come in pairs and the workgroup is one pair, so both waves leave together
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
 	if (lc.hedge)

@@ -345,6 +345,44 @@ def test_optimistic_inverse_around_its_proof_bound(po):
                         assert np.array_equal(got, want), (wavelet, color, bound, pattern, framing)
 
 
+def test_wide_strips_121_to_128_columns(po, path_mode):
+    """Tiles of 121..128 coefficient columns run as ONE strip without halo lanes (ako_stream.hip.h: lane_columns,
+    border_values): every wavelet and wrap, even and odd widths, 4 / 3 / 1 channels, 256-px tiles (the shape of
+    configs[4] in 256-px tiles), adversarial streams, lifting-only planes."""
+    nrng = np.random.default_rng(909)
+    cases = [(256, 40, 4, 0), (255, 33, 4, 0), (252, 34, 4, 0), (251, 35, 3, 0), (248, 36, 1, 0), (247, 64, 4, 0),
+             (244, 33, 4, 0), (243, 34, 2, 0), (700, 300, 4, 256), (512, 256, 3, 256), (256, 256, 4, 0)]
+    for (w, h, ch, td) in cases:
+        for wavelet in (0, 1, 2):
+            for wrap in range(4):
+                q = int(nrng.choice([0, 16]))
+                img = nrng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+                s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=q // 2, tiles=td)
+                ob, st = po.encode_image(s, img)
+                assert st == 0
+                body = hip_encode_body(img, s)
+                assert np.array_equal(body, ob[16:]), (w, h, ch, td, wavelet, wrap, q)
+                od, os_, _ = po.decode_image(ob)
+                dec = hip_decode_body(ob[16:], os_, ch, w, h)
+                assert np.array_equal(dec, od), (w, h, ch, td, wavelet, wrap, q)
+                blob2 = ob.copy()
+                blob2[16:] = nrng.integers(0, 256, ob.size - 16, dtype=np.uint8)
+                od2, _, st2 = po.decode_image(blob2)
+                assert st2 == 0
+                dec2 = hip_decode_body(blob2[16:], os_, ch, w, h)
+                assert np.array_equal(dec2, od2), ("adversarial", w, h, ch, td, wavelet, wrap)
+    for (w, h, wv, wrap) in [(256, 40, 0, 0), (252, 36, 0, 2), (255, 37, 1, 1), (244, 50, 0, 3), (247, 33, 2, 2)]:
+        plane = po.gen_plane(w * h, seed=w + h).reshape(1, h, w)
+        sp = api.settings(wavelet=wv, wrap=wrap, compression=2, q=0, g=0, color=2)
+        with api.Plan(sp, 1, w, h, batch=1, planes_i16=True) as plan:
+            d = torch.from_numpy(plane.copy()).cuda().reshape(1, 1, h, w)
+            st = plan.encode(d)
+            back = plan.decode(st)
+            plan.synchronize()
+            assert torch.equal(back, d), (w, h, wv, wrap)
+            assert np.array_equal(st.cpu().numpy().reshape(-1), po.lift_plane(wv, wrap, plane[0])), (w, h, wv, wrap)
+
+
 def test_adversarial_streams_decode_alike(po, path_mode):
     """Full-range int16 coefficient streams: every int16 wrap-around in the inverse path must agree."""
     rng = random.Random(77)
