@@ -173,6 +173,10 @@ def lib() -> C.CDLL:
     L.akoHostKagariEncode.argtypes = [sz, sz, vp, vp]
     L.akoHostKagariDecode.restype = sz
     L.akoHostKagariDecode.argtypes = [sz, sz, sz, vp, vp]
+    L.akoHostSynthImage.restype = None
+    L.akoHostSynthImage.argtypes = [C.c_int, C.c_uint32, sz, sz, vp]
+    L.akoHostSynthPlane.restype = None
+    L.akoHostSynthPlane.argtypes = [C.c_uint32, sz, vp]
     _lib = L
     return L
 
@@ -199,6 +203,24 @@ def device_count() -> int:
 
 def last_error() -> str:
     return lib().akoHipLastError().decode()
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic inputs of the benchmark configurations, generated by the library's host side
+# ---------------------------------------------------------------------------------------------
+
+def synth_image(generator: int, w: int, h: int, seed: int = 0x9E3779B9) -> np.ndarray:
+    """RGBA image (h, w, 4) uint8: generator 0 = G0 "smooth", 1 = G1 "noise"."""
+    img = np.empty((h, w, 4), dtype=np.uint8)
+    lib().akoHostSynthImage(generator, seed & 0xFFFFFFFF, w, h, img.ctypes.data_as(C.c_void_p))
+    return img
+
+
+def synth_plane(n: int, seed: int = 0x9E3779B9) -> np.ndarray:
+    """G2: n int16 samples in [-512, 511]."""
+    p = np.empty(n, dtype=np.int16)
+    lib().akoHostSynthPlane(seed & 0xFFFFFFFF, n, p.ctypes.data_as(C.c_void_p))
+    return p
 
 
 # ---------------------------------------------------------------------------------------------

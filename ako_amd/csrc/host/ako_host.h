@@ -51,4 +51,8 @@ AKO_API int akoHostKagariTokensAppend(struct akoKagariTokens* dst, const struct 
                                       uint32_t literal_base);
 AKO_API void akoHostKagariTokensFree(struct akoKagariTokens* tok);
 
+/* ako_synth.c: synthetic benchmark inputs */
+AKO_API void akoHostSynthImage(int generator, uint32_t seed, size_t w, size_t h, uint8_t* rgba);
+AKO_API void akoHostSynthPlane(uint32_t seed, size_t n, int16_t* plane);
+
 #endif

@@ -360,3 +360,16 @@ def test_kagari_decoder_verdicts_on_damaged_payloads_match_the_oracle(po):
                     agree_nonzero += 1
                     assert np.array_equal(o1[:values], o2[:values])
     assert agree_nonzero > 50  # damaged-but-accepted streams were among them
+
+
+def test_synthetic_generators_match_the_oracle_and_the_survey_anchors(po, golden_sums):
+    """bench.py draws its inputs from the library's host side (akoHostSynthImage / akoHostSynthPlane); the oracle
+    keeps its own restatement of SURVEY 8d's generators.  The two must agree, and G0 must hit the input Adler-32
+    the compiled reference was fed for the anchor table (64x64 -> 15173ae6, 100x75 -> 189d0ecc)."""
+    for gen in (0, 1):
+        for (w, h, seed) in [(64, 64, 0x9E3779B9), (100, 75, 5), (517, 233, 0x9E3779B9 + 3), (1, 1, 1)]:
+            assert np.array_equal(api.synth_image(gen, w, h, seed), po.gen_image(gen, w, h, seed=seed))
+    assert np.array_equal(api.synth_plane(10000, 77), po.gen_plane(10000, seed=77))
+    assert f"{po.adler32(api.synth_image(0, 64, 64)):08x}" == "15173ae6"
+    assert f"{po.adler32(api.synth_image(0, 100, 75)):08x}" == "189d0ecc"
+    assert f"{po.adler32(api.synth_image(1, 100, 75)):08x}" == "57cbae7c"
