@@ -173,6 +173,23 @@ def lib() -> C.CDLL:
     L.akoHostKagariEncode.argtypes = [sz, sz, vp, vp]
     L.akoHostKagariDecode.restype = sz
     L.akoHostKagariDecode.argtypes = [sz, sz, sz, vp, vp]
+    L.akoHipThreadRelease.restype = None
+    L.akoHipThreadRelease.argtypes = []
+    L.akoHipTuningSignature.restype = C.c_uint64
+    L.akoHipBatchCreate.restype = vp
+    L.akoHipBatchCreate.argtypes = [C.POINTER(C.c_int), sz, sz, C.POINTER(Settings), sz, sz, sz, C.POINTER(C.c_int)]
+    L.akoHipBatchDestroy.restype = None
+    L.akoHipBatchDestroy.argtypes = [vp]
+    L.akoHipBatchLanes.restype = sz
+    L.akoHipBatchLanes.argtypes = [vp]
+    L.akoHipEncodeBatch.restype = C.c_int
+    L.akoHipEncodeBatch.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int)]
+    L.akoHipDecodeBatch.restype = C.c_int
+    L.akoHipDecodeBatch.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(C.c_int)]
+    L.akoHipHostAlloc.restype = vp
+    L.akoHipHostAlloc.argtypes = [sz]
+    L.akoHipHostFree.restype = None
+    L.akoHipHostFree.argtypes = [vp]
     L.akoHostSynthImage.restype = None
     L.akoHostSynthImage.argtypes = [C.c_int, C.c_uint32, sz, sz, vp]
     L.akoHostSynthPlane.restype = None
@@ -421,3 +438,71 @@ class Plan:
         n = lib().akoHipPlanKernelRecords(self._p, 1 if decode else 0, buf, 8192)
         return [dict(name=buf[i].name.decode(), ms=buf[i].ms, level=buf[i].level, group=buf[i].group,
                      units=buf[i].units, bytes_rd=buf[i].bytes_rd, bytes_wr=buf[i].bytes_wr) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------
+# batched host API (include/ako_hip.h: akoHipBatch*): arrays of equally shaped images, all devices
+# ---------------------------------------------------------------------------------------------
+
+class Batch:
+    """akoHipBatch wrapper: host images -> .ako blobs -> host images, many at a time, over the lanes of one or more
+    devices (the caller of tools/akoenc.cpp:112-217 for a whole array; BASELINE configs[3])."""
+
+    def __init__(self, s: Settings, channels: int, w: int, h: int, devices=None, lanes_per_device: int = 0):
+        self.channels, self.w, self.h = channels, w, h
+        devs = list(devices) if devices else [0]
+        arr = (C.c_int * len(devs))(*devs)
+        st = C.c_int(-1)
+        self._b = lib().akoHipBatchCreate(arr, len(devs), lanes_per_device, C.byref(s), channels, w, h, C.byref(st))
+        if not self._b:
+            raise AkoError(st.value, "akoHipBatchCreate", last_error())
+        self.lanes = lib().akoHipBatchLanes(self._b)
+
+    def close(self):
+        if getattr(self, "_b", None):
+            lib().akoHipBatchDestroy(self._b)
+            self._b = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        if lib is None:
+            return
+        self.close()
+
+    def encode(self, images):
+        """images: sequence of (h, w, channels) uint8 arrays -> (list of blobs | None, list of status)."""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        for im in imgs:
+            assert im.size == self.w * self.h * self.channels
+        n = len(imgs)
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        out = (C.c_void_p * n)()
+        sizes = (C.c_size_t * n)()
+        st = (C.c_int * n)()
+        lib().akoHipEncodeBatch(self._b, n, ptrs, out, sizes, st)
+        blobs = []
+        for i in range(n):
+            if st[i] == 0 and out[i]:
+                blobs.append(np.ctypeslib.as_array(C.cast(out[i], C.POINTER(C.c_uint8)), shape=(sizes[i],)).copy())
+                lib().akoDefaultFree(out[i])
+            else:
+                blobs.append(None)
+        return blobs, list(st)
+
+    def decode(self, blobs):
+        """blobs of images of this batch's shape -> (list of (h, w, channels) arrays | None, list of status)."""
+        bl = [np.ascontiguousarray(np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else b, dtype=np.uint8)
+              for b in blobs]
+        n = len(bl)
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bl])
+        sizes = (C.c_size_t * n)(*[b.size for b in bl])
+        outs = [np.empty((self.h, self.w, self.channels), dtype=np.uint8) for _ in range(n)]
+        optr = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        st = (C.c_int * n)()
+        lib().akoHipDecodeBatch(self._b, n, ptrs, sizes, optr, st)
+        return [o if st[i] == 0 else None for i, o in enumerate(outs)], list(st)

@@ -17,9 +17,9 @@ OUT = os.path.join(HERE, "libako.so")
 OBJ = os.path.join(HERE, "csrc", "build")
 
 HIP_SOURCES = ["ako_plan.hip"]
-HIP_HEADERS = ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_tail.hip.h", "ako_kagari.hip.h"]
+HIP_HEADERS = ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_tail.hip.h", "ako_kagari.hip.h", "ako_requant.hip.h"]
 C_SOURCES = ["host/ako_quant.c", "host/ako_head.c", "host/ako_misc.c", "host/ako_kagari.c", "host/ako_codec.c",
-             "host/ako_synth.c"]
+             "host/ako_synth.c", "host/ako_batch.c"]
 C_HEADERS = ["host/ako_host.h", "../../include/ako.h", "../../include/ako_hip.h"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -9,6 +9,7 @@
 #include "ako_stream.hip.h"
 #include "ako_tail.hip.h"
 #include "ako_kagari.hip.h"
+#include "ako_requant.hip.h"
 
 #include "../../include/ako_hip.h"
 
@@ -113,9 +114,49 @@ struct KagariState
 
 }  // namespace
 
+// Tuning / test knobs, read from the environment ONCE when a plan is created (a launch path that called getenv per
+// level and call was neither cheap for small images nor safe against a concurrent setenv).
+struct Tuning
+{
+	int path = 0;          // AKO_HIP_PATH: 0 auto, 1 generic (window engine), 2 stream wherever legal
+	int tail = 1;          // AKO_HIP_TAIL: 0 none, 1 window-engine tail, 2 segment-engine tail
+	int tail_max = 0;      // AKO_HIP_TAIL_MAX: hand only levels this small to the tail (0 = default)
+	bool wide = true;      // AKO_HIP_WIDE=0: no halo-free 121..128 column strips
+	int seg_rows = 0;      // AKO_HIP_SEG_ROWS: rows per segment of the streaming kernels (0 = chosen per level)
+	int seg_rows_big = 0;  // AKO_HIP_SEG_ROWS_BIG: the same for levels of >= 1024 columns only
+	int seg_rows_small = 0;  // AKO_HIP_SEG_ROWS_SMALL: shortest segment of levels below 1024 columns (0 = default)
+	bool opt = true;       // AKO_HIP_OPT=0: exact int16-wrapping inverse alone (no optimistic fp32 launch)
+	bool staged = true;    // AKO_HIP_STAGED=0: no planar staging of 1-3 / 5+ channel u8 images
+	bool deep = true;      // AKO_HIP_DEEP=0: small levels keep the running two-slot prefetch
+	uint32_t dbg = 0;      // AKO_HIP_DBG bits (kernel side experiments)
+
+	static Tuning from_env()
+	{
+		Tuning t;
+		auto num = [](const char* name, int dflt) {
+			const char* e = getenv(name);
+			return (e != nullptr && *e != '\0') ? atoi(e) : dflt;
+		};
+		if (const char* e = getenv("AKO_HIP_PATH"))
+			t.path = (strcmp(e, "generic") == 0) ? 1 : ((strcmp(e, "stream") == 0) ? 2 : 0);
+		t.tail = num("AKO_HIP_TAIL", 1);
+		t.tail_max = num("AKO_HIP_TAIL_MAX", 0);
+		t.wide = num("AKO_HIP_WIDE", 1) != 0;
+		t.seg_rows = num("AKO_HIP_SEG_ROWS", 0);
+		t.seg_rows_big = num("AKO_HIP_SEG_ROWS_BIG", 0);
+		t.seg_rows_small = num("AKO_HIP_SEG_ROWS_SMALL", 0);
+		t.opt = num("AKO_HIP_OPT", 1) != 0;
+		t.staged = num("AKO_HIP_STAGED", 1) != 0;
+		t.deep = num("AKO_HIP_DEEP", 1) != 0;
+		t.dbg = (uint32_t)num("AKO_HIP_DBG", 0);
+		return t;
+	}
+};
+
 struct akoHipPlan
 {
 	int device = 0;
+	Tuning tune;
 	hipStream_t stream = nullptr;
 	struct akoSettings s;
 	size_t channels = 0, w = 0, h = 0, batch = 0;
@@ -142,6 +183,10 @@ struct akoHipPlan
 	std::vector<Pending> pending[2];
 	KagariState* kg = nullptr;
 	bool owns_stream = false;
+	// ratio search (akoHipRequantize): the re-quantized streams and the segment table of the last candidate
+	int16_t* d_requant = nullptr;
+	void* d_rq_segments = nullptr;
+	size_t rq_segment_capacity = 0;
 };
 
 namespace
@@ -269,8 +314,7 @@ void fill_common(LevelParams& P, const akoHipPlan* pl, const Group& g, const Lev
 	P.q_luma = L.q[0], P.g_luma = L.g[0], P.q_chroma = L.q[1], P.g_chroma = L.g[1];
 	P.rq_luma = (float)((1.0 / (double)(L.q[0] < 1 ? 1 : L.q[0])) * (1.0 + 1e-6));
 	P.rq_chroma = (float)((1.0 / (double)(L.q[1] < 1 ? 1 : L.q[1])) * (1.0 + 1e-6));
-	if (const char* e = getenv("AKO_HIP_DBG"))
-		P.dbg = (uint32_t)atoi(e);
+	P.dbg = pl->tune.dbg;
 }
 
 template <bool U8>
@@ -298,16 +342,9 @@ void launch_inverse(int kind, const LevelParams& P, uint32_t blocks, size_t smem
 // ---- choice between the window engine and the register-streaming kernels ----------------------
 enum { PATH_AUTO = 0, PATH_GENERIC = 1, PATH_STREAM = 2 };
 
-int path_mode()
+int path_mode(const akoHipPlan* pl)
 {
-	const char* e = getenv("AKO_HIP_PATH");
-	if (e == nullptr)
-		return PATH_AUTO;
-	if (strcmp(e, "generic") == 0)
-		return PATH_GENERIC;
-	if (strcmp(e, "stream") == 0)
-		return PATH_STREAM;
-	return PATH_AUTO;
+	return pl->tune.path;
 }
 
 bool many_planes(const akoHipPlan* pl)
@@ -338,7 +375,7 @@ bool stream_width_ok(const akoHipPlan* pl, const LevelGeom& L)
 
 bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 {
-	const int mode = path_mode();
+	const int mode = path_mode(pl);
 	if (mode == PATH_GENERIC)
 		return false;
 	if (!stream_width_ok(pl, L) || L.th < 2)
@@ -359,21 +396,21 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 	return L.tw >= 64 && L.th >= 12;
 }
 
-StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit, bool u8)
+// row slots a "deep prefetch" wave fetches up front and then works through (exactly that many, no loop):
+// segments of <= 6 rows + 6 halo slots, or of <= 2 rows
+constexpr int DEEP_SLOTS = 12, DEEP_SLOTS_SHORT = 8;
+
+StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8)
 {
 	StreamGeom G;
 	G.strips = (L.tw + SNET - 1) / SNET;
 	G.wide = 0;
 	// 121..128 coefficient columns (an even number): one strip without halo lanes instead of two
-	const char* wide_env = getenv("AKO_HIP_WIDE");
-	if (L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && !(wide_env != nullptr && atoi(wide_env) == 0))
+	if (L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && pl->tune.wide)
 		G.strips = 1, G.wide = 1;
-	uint32_t seg_rows = 0;
-	if (const char* e = getenv("AKO_HIP_SEG_ROWS"))
-		seg_rows = (uint32_t)atoi(e);
-	if (const char* e = getenv("AKO_HIP_SEG_ROWS_BIG"))  // tuning aid: levels with >= 1024 columns only
-		if (L.tw >= 1024)
-			seg_rows = (uint32_t)atoi(e);
+	uint32_t seg_rows = (uint32_t)pl->tune.seg_rows;
+	if (pl->tune.seg_rows_big != 0 && L.tw >= 1024)  // tuning aid: levels with >= 1024 columns only
+		seg_rows = (uint32_t)pl->tune.seg_rows_big;
 	if (seg_rows == 0)
 	{
 		// aim at two rounds of resident waves: the u8 kernels run 3 waves per SIMD (6144 waves), the int16
@@ -385,7 +422,7 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit, bool
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
-		const uint32_t floor_rows = (L.tw >= 1024) ? 24 : 6;
+		const uint32_t floor_rows = (L.tw >= 1024) ? 24 : (pl->tune.seg_rows_small > 0 ? (uint32_t)pl->tune.seg_rows_small : 2);
 		if (seg_rows < floor_rows)
 			seg_rows = floor_rows;
 	}
@@ -396,12 +433,20 @@ StreamGeom stream_geometry(const LevelGeom& L, uint64_t waves_per_row_unit, bool
 	return G;
 }
 
-template <int NPL, bool U8>
+// int16 levels whose segments fit: every row slot of a wave's segment is fetched before the first is used
+int deep_prefetch(const akoHipPlan* pl, const StreamGeom& G, bool u8)
+{
+	if (u8 || !pl->tune.deep || G.seg_rows + 6 > (uint32_t)DEEP_SLOTS)
+		return 0;
+	return (G.seg_rows + 6 <= (uint32_t)DEEP_SLOTS_SHORT) ? DEEP_SLOTS_SHORT : DEEP_SLOTS;
+}
+
+template <int NPL, bool U8, int DEEP>
 void launch_forward_stream(int kind, bool narrow, const LevelParams& P, const StreamGeom& G, uint32_t blocks,
                            hipStream_t st)
 {
 #define AKO_FS(K, N)                                                                                         \
-	hipLaunchKernelGGL((k_forward_stream<K, NPL, U8, N>), dim3(blocks), dim3(THREADS), 0, st, P, G)
+	hipLaunchKernelGGL((k_forward_stream<K, NPL, U8, N, DEEP>), dim3(blocks), dim3(THREADS), 0, st, P, G)
 	if (kind == K_DD137)
 	{
 		if (narrow) AKO_FS(K_DD137, true); else AKO_FS(K_DD137, false);
@@ -415,16 +460,16 @@ void launch_forward_stream(int kind, bool narrow, const LevelParams& P, const St
 #undef AKO_FS
 }
 
-template <int NPL, bool U8, bool OPT>
+template <int NPL, bool U8, bool OPT, int DEEP>
 void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, hipStream_t st)
 {
 	const dim3 threads(U8 ? 128 : THREADS);  // U8: the workgroup is one pair of waves (LDS plane swap)
 	if (kind == K_DD137)
-		hipLaunchKernelGGL((k_inverse_stream<K_DD137, NPL, U8, OPT>), dim3(blocks), threads, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_DD137, NPL, U8, OPT, DEEP>), dim3(blocks), threads, 0, st, P, G);
 	else if (kind == K_CDF53)
-		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8, OPT>), dim3(blocks), threads, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8, OPT, DEEP>), dim3(blocks), threads, 0, st, P, G);
 	else
-		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8, OPT>), dim3(blocks), threads, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8, OPT, DEEP>), dim3(blocks), threads, 0, st, P, G);
 }
 
 int check_blocks(uint64_t blocks)
@@ -446,10 +491,8 @@ uint64_t scratch_plane_elems(const Group& g, int which)
 // slower than 1 on every workload of bench.py).  AKO_HIP_TAIL=0 / 1 / 2 forces none / one.
 int tail_engine(const akoHipPlan* pl, const Group& g)
 {
-	(void)pl, (void)g;
-	if (const char* e = getenv("AKO_HIP_TAIL"))
-		return atoi(e);
-	return 1;
+	(void)g;
+	return pl->tune.tail;
 }
 
 // first level handled by the fused in-LDS tail kernel (nl = none).  Level 0 of a u8 image never is.
@@ -460,11 +503,10 @@ size_t tail_start(const akoHipPlan* pl, const Group& g)
 	if (engine == 0)
 		return nl;
 	uint32_t lim = (engine == 2) ? (uint32_t)SEG_TAIL_MAX : (uint32_t)TAIL_MAX;
-	if (many_planes(pl) && path_mode() != PATH_GENERIC)
+	if (many_planes(pl) && path_mode(pl) != PATH_GENERIC)
 		lim = 8;  // see stream_eligible(): only what the streaming kernels cannot take
-	if (const char* e = getenv("AKO_HIP_TAIL_MAX"))  // tuning aid: hand smaller levels only to the tail
-		if (atoi(e) >= 4 && (uint32_t)atoi(e) < lim)
-			lim = (uint32_t)atoi(e);
+	if (pl->tune.tail_max >= 4 && (uint32_t)pl->tune.tail_max < lim)  // tuning aid: hand smaller levels only to the tail
+		lim = (uint32_t)pl->tune.tail_max;
 	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
 	for (size_t l = planes ? 0 : 1; l < nl; l++)
 		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim)
@@ -612,11 +654,10 @@ bool staged_level0(const akoHipPlan* pl, const Group& g)
 {
 	if ((pl->flags & AKO_HIP_PLAN_PLANES_I16) || pl->channels == 4 || g.levels.empty())
 		return false;
-	if (pl->s.wavelet == AKO_WAVELET_NONE || path_mode() == PATH_GENERIC)
+	if (pl->s.wavelet == AKO_WAVELET_NONE || path_mode(pl) == PATH_GENERIC)
 		return false;
-	if (const char* e = getenv("AKO_HIP_STAGED"))
-		if (atoi(e) == 0)
-			return false;
+	if (!pl->tune.staged)
+		return false;
 	const LevelGeom& L = g.levels[0];
 	return stream_width_ok(pl, L) && L.th >= 2 && L.tw >= 64 && L.th >= 12;
 }
@@ -709,7 +750,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
-				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts, u8);
+				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
 				if (int rc = check_blocks(blocks))
@@ -718,13 +759,18 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				// data provably stays inside int16: levels 0 and 1 (|Y| <= 510 -> level 0 output <= 2953 ->
 				// level 1 output <= 17097).  Those levels run on the exact fp32 pipeline.
 				const bool narrow = planes || l >= 2;
+				const int deep = deep_prefetch(pl, G, u8);
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_forward_stream<2, true>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+					launch_forward_stream<2, true, 0>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+				else if (deep == DEEP_SLOTS_SHORT)
+					launch_forward_stream<1, false, DEEP_SLOTS_SHORT>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+				else if (deep)
+					launch_forward_stream<1, false, DEEP_SLOTS>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else
-					launch_forward_stream<1, false>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
-				snprintf(name, sizeof name, "fwd_stream_%s%s", kind_name(L.kind), u8 ? "_u8" : "");
+					launch_forward_stream<1, false, 0>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+				snprintf(name, sizeof name, "fwd_stream_%s%s%s", kind_name(L.kind), u8 ? "_u8" : "", deep ? "_deep" : "");
 			}
 			else
 			{
@@ -823,27 +869,25 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
-				const StreamGeom G = stream_geometry(L, (uint64_t)P.plane_groups * insts, u8);
+				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint32_t waves_per_block = u8 ? 2 : (THREADS / 64);
+				const int deep = deep_prefetch(pl, G, u8);
 				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
 					return rc;
 				// u8 side: optimistic fp32 launch, then the exact kernel which only works if the first one
 				// raised the overflow flag (AKO_HIP_OPT=0 runs the exact kernel alone)
-				const char* opt_env = getenv("AKO_HIP_OPT");
-				const bool optimistic = u8 && !(opt_env != nullptr && atoi(opt_env) == 0);
+				const bool optimistic = u8 && pl->tune.opt;
 				if (optimistic)
 				{
-					if (pl->d_flags == nullptr)
-						HIP_TRY(hipMalloc((void**)&pl->d_flags, 64 * sizeof(int32_t)));
 					const size_t slot = (gi * 8 + l) % 64;
 					HIP_TRY(hipMemsetAsync(pl->d_flags + slot, 0, sizeof(int32_t), pl->stream));
 					P.ovf_flag = pl->d_flags + slot;
 					Launch LO{pl, 1};
 					if (int rc = LO.begin())
 						return rc;
-					launch_inverse_stream<2, true, true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_stream<2, true, true, 0>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 					snprintf(name, sizeof name, "inv_stream_%s_u8", kind_name(L.kind));
 					const uint64_t smp = (uint64_t)L.cw * L.ch * pl->channels * insts;
 					const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
@@ -853,10 +897,14 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_inverse_stream<2, true, false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_stream<2, true, false, 0>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+				else if (deep == DEEP_SLOTS_SHORT)
+					launch_inverse_stream<1, false, false, DEEP_SLOTS_SHORT>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+				else if (deep)
+					launch_inverse_stream<1, false, false, DEEP_SLOTS>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else
-					launch_inverse_stream<1, false, false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
-				snprintf(name, sizeof name, "inv_stream_%s%s%s", kind_name(L.kind), u8 ? "_u8" : "",
+					launch_inverse_stream<1, false, false, 0>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+				snprintf(name, sizeof name, "inv_stream_%s%s%s", kind_name(L.kind), u8 ? "_u8" : (deep ? "_deep" : ""),
 				         optimistic ? "_exact_if_flagged" : "");
 			}
 			else
@@ -887,6 +935,21 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 
 }  // namespace
 
+// nothing may unwind through the C callers of the C-ABI: a failed host allocation (std::bad_alloc from a vector)
+// becomes AKO_NO_ENOUGH_MEMORY
+template <typename F>
+static int guarded(F&& body)
+{
+	try
+	{
+		return body();
+	}
+	catch (...)
+	{
+		return fail(AKO_NO_ENOUGH_MEMORY, "out of host memory%s%s");
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------
@@ -908,6 +971,18 @@ int akoHipDeviceCount(void)
 const char* akoHipLastError(void)
 {
 	return g_last_error.c_str();
+}
+
+// What the tuning knobs of the environment say right now, folded into one word: the drivers keep a thread's plan
+// between calls and must not reuse it once a knob has changed (plans read the knobs when they are created).
+uint64_t akoHipTuningSignature(void)
+{
+	const Tuning t = Tuning::from_env();
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, (int)t.dbg};
+	uint64_t h = 1469598103934665603ull;
+	for (int x : v)
+		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;
+	return h;
 }
 
 enum akoColor akoHipEffectiveColor(const struct akoSettings* s)  // encode.c:59-64
@@ -935,6 +1010,7 @@ akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, siz
 		goto failed;              \
 	} while (0)
 
+	try  // nothing may unwind through the C callers: std::bad_alloc becomes AKO_NO_ENOUGH_MEMORY
 	{
 		if (settings == nullptr || batch == 0)
 			PLAN_FAIL(AKO_INVALID_INPUT, "null settings or empty batch");
@@ -951,6 +1027,17 @@ akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, siz
 			PLAN_FAIL(AKO_INVALID_WAVELET_TRANSFORMATION, "invalid wavelet");
 		if ((int)settings->color < 0 || (int)settings->color > 3)
 			PLAN_FAIL(AKO_INVALID_COLOR_TRANSFORMATION, "invalid colour transformation");
+
+		// sizes that do not fit: 64-bit products must not wrap (w * h * channels, the streams, the scratch planes),
+		// and the tile table must stay a table (a forged head could ask for 10^17 tiles of 8 pixels)
+		{
+			size_t samples = 0, bytes = 0, n_tiles = 0;
+			const size_t tiles_x = td ? (image_w + td - 1) / td : 1, tiles_y = td ? (image_h + td - 1) / td : 1;
+			if (__builtin_mul_overflow(image_w, image_h, &samples) || __builtin_mul_overflow(samples, channels, &samples) ||
+			    __builtin_mul_overflow(samples, batch, &samples) || __builtin_mul_overflow(samples, (size_t)4, &bytes) ||
+			    bytes > ((size_t)1 << 47) || __builtin_mul_overflow(tiles_x, tiles_y, &n_tiles) || n_tiles > ((size_t)1 << 28))
+				PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "image too large for a device plan");
+		}
 
 		int ndev = 0;
 		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -973,6 +1060,7 @@ akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, siz
 			pl->owns_stream = true;
 		}
 		pl->s = *settings;
+		pl->tune = Tuning::from_env();
 		pl->channels = channels, pl->w = image_w, pl->h = image_h, pl->batch = batch, pl->flags = flags;
 		if (flags & AKO_HIP_PLAN_PLANES_I16)
 			pl->s.color = AKO_COLOR_NONE;
@@ -1023,6 +1111,18 @@ akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, siz
 			if (pl->scratch_elems[which] != 0 &&
 			    hipMalloc((void**)&pl->scratch[which], pl->scratch_elems[which] * sizeof(int16_t)) != hipSuccess)
 				PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(low-pass scratch) failed");
+		// everything a first call would otherwise allocate inside its (possibly timed) launch sequence
+		if (hipMalloc((void**)&pl->d_flags, 64 * sizeof(int32_t)) != hipSuccess)
+			PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(overflow flags) failed");
+		for (const Group& g : pl->groups)
+			if (pl->planes0 == nullptr && staged_level0(pl, g) && tail_start(pl, g) > 0 && ensure_planes0(pl) != 0)
+				PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(planar staging image) failed");
+	}
+	catch (...)
+	{
+		st = AKO_NO_ENOUGH_MEMORY;
+		g_last_error = "out of host memory while building the plan";
+		goto failed;
 	}
 
 	if (out_status)
@@ -1058,6 +1158,10 @@ void akoHipPlanDestroy(akoHipPlan* pl)
 		(void)hipFree(pl->d_flags);
 	if (pl->planes0)
 		(void)hipFree(pl->planes0);
+	if (pl->d_requant)
+		(void)hipFree(pl->d_requant);
+	if (pl->d_rq_segments)
+		(void)hipFree(pl->d_rq_segments);
 	if (pl->kg)
 	{
 		KagariState* k = pl->kg;
@@ -1143,7 +1247,7 @@ int akoHipEncode(akoHipPlan* pl, const void* d_images, void* d_streams)
 	if (!pl || !d_images || !d_streams)
 		return fail(AKO_INVALID_INPUT, "null argument%s%s");
 	HIP_TRY(hipSetDevice(pl->device));
-	return run_encode(pl, d_images, d_streams);
+	return guarded([&] { return run_encode(pl, d_images, d_streams); });
 }
 
 int akoHipDecode(akoHipPlan* pl, const void* d_streams, void* d_images)
@@ -1151,7 +1255,24 @@ int akoHipDecode(akoHipPlan* pl, const void* d_streams, void* d_images)
 	if (!pl || !d_images || !d_streams)
 		return fail(AKO_INVALID_INPUT, "null argument%s%s");
 	HIP_TRY(hipSetDevice(pl->device));
-	return run_decode(pl, d_streams, d_images);
+	return guarded([&] { return run_decode(pl, d_streams, d_images); });
+}
+
+void* akoHipHostAlloc(size_t bytes)
+{
+	void* p = nullptr;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return p;
+}
+
+void akoHipHostFree(void* p)
+{
+	if (p)
+		(void)hipHostFree(p);
 }
 
 int akoHipSynchronize(akoHipPlan* pl)
@@ -1302,7 +1423,12 @@ int akoHipEncodeUpload(akoHipPlan* pl, const void* h_images)
 	return akoHipEncode(pl, pl->d_img, pl->d_stream);
 }
 
+static int kagari_encode(akoHipPlan* pl, const void* d_streams, size_t image, size_t* body_bytes, size_t* failed_tile);
 int akoHipKagariEncode(akoHipPlan* pl, const void* d_streams, size_t image, size_t* body_bytes, size_t* failed_tile)
+{
+	return guarded([&] { return kagari_encode(pl, d_streams, image, body_bytes, failed_tile); });
+}
+static int kagari_encode(akoHipPlan* pl, const void* d_streams, size_t image, size_t* body_bytes, size_t* failed_tile)
 {
 	if (!pl || image >= pl->batch)
 		return fail(AKO_INVALID_INPUT, "null plan or image index out of range%s%s");
@@ -1389,6 +1515,101 @@ int akoHipKagariEncode(akoHipPlan* pl, const void* d_streams, size_t image, size
 	return 0;
 }
 
+// ---- ratio search support: one transform, many quantizations -------------------------------------
+
+void* akoHipPlanDeviceImages(akoHipPlan* pl)
+{
+	if (!pl || hipSetDevice(pl->device) != hipSuccess || ensure_staging(pl) != 0)
+		return nullptr;
+	return pl->d_img;
+}
+
+void* akoHipPlanDeviceStreams(akoHipPlan* pl)
+{
+	if (!pl || hipSetDevice(pl->device) != hipSuccess || ensure_staging(pl) != 0)
+		return nullptr;
+	return pl->d_stream;
+}
+
+static int requantize(akoHipPlan* pl, int quantization, int gate, const void* d_unquantized, void** d_out)
+{
+	if (!pl)
+		return fail(AKO_INVALID_INPUT, "null plan%s%s");
+	if ((pl->flags & AKO_HIP_PLAN_PLANES_I16) || pl->s.wavelet == AKO_WAVELET_NONE)
+		return fail(AKO_INVALID_INPUT, "nothing to re-quantize: the plan has no coefficient groups%s%s");
+	if (pl->s.quantization > 0 || pl->s.gate > 0)
+		return fail(AKO_INVALID_INPUT, "akoHipRequantize works on the streams of a plan created with quantization 0 and gate 0%s%s");
+	HIP_TRY(hipSetDevice(pl->device));
+	if (d_unquantized == nullptr)
+	{
+		if (int rc = ensure_staging(pl))
+			return rc;
+		d_unquantized = pl->d_stream;
+	}
+	if (!pl->d_requant)
+		if (hipMalloc((void**)&pl->d_requant, akoHipPlanStreamBytes(pl) * pl->batch) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(re-quantized streams) failed%s%s");
+
+	// segment table: per tile the low-pass section (copied) and one group per level and plane, in stream order
+	std::vector<RqSegment> segs;
+	uint32_t blocks = 0;
+	auto push = [&](uint64_t start, uint64_t count, int q, int g) {
+		RqSegment s;
+		s.start = start, s.count = count, s.q = q, s.g = g;
+		s.rq = (float)((1.0 / (double)(q < 1 ? 1 : q)) * (1.0 + 1e-6));
+		s.first_block = blocks;
+		blocks += (uint32_t)((count + RQ_CHUNK - 1) / RQ_CHUNK);
+		segs.push_back(s);
+	};
+	for (const TileInfo& ti : pl->tiles)
+	{
+		const Group& g = pl->groups[ti.group];
+		const uint64_t t0 = ti.stream_off / 2;
+		push(t0, (uint64_t)g.fw * g.fh * pl->channels, 0, 0);
+		for (size_t l = g.levels.size(); l-- > 0;)
+		{
+			const LevelGeom& L = g.levels[l];
+			for (size_t p = 0; p < pl->channels; p++)
+			{
+				const int mul = (p == 0) ? 1 : pl->s.chroma_loss + 1;  // lifting.c:202-211
+				const int q = akoHostQuantStep(quantization, mul, g.tile_w, g.tile_h, L.cw, L.ch);
+				const int gt = akoHostGateStep(gate, mul, g.tile_w, g.tile_h, L.cw, L.ch);
+				push(t0 + L.grp_off[p], 1 + 3 * (uint64_t)L.tw * L.th, q < 1 ? 1 : q, gt);
+			}
+		}
+	}
+	if ((uint64_t)blocks * pl->batch > 0x7FFFFFFFull)
+		return fail(AKO_ERROR, "launch too large for one grid%s%s");
+	if (segs.size() > pl->rq_segment_capacity)
+	{
+		if (pl->d_rq_segments)
+			(void)hipFree(pl->d_rq_segments), pl->d_rq_segments = nullptr;
+		pl->rq_segment_capacity = 0;
+		if (hipMalloc(&pl->d_rq_segments, segs.size() * sizeof(RqSegment)) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipMalloc(segment table) failed%s%s");
+		pl->rq_segment_capacity = segs.size();
+	}
+	HIP_TRY(hipMemcpyAsync(pl->d_rq_segments, segs.data(), segs.size() * sizeof(RqSegment), hipMemcpyHostToDevice, pl->stream));
+	Launch LA{pl, 0};
+	if (int rc = LA.begin())
+		return rc;
+	hipLaunchKernelGGL(k_requantize, dim3(blocks * (uint32_t)pl->batch), dim3(RQ_THREADS), 0, pl->stream,
+	                   (const int16_t*)d_unquantized, pl->d_requant, (const RqSegment*)pl->d_rq_segments, (uint32_t)segs.size(),
+	                   (uint64_t)pl->stream_values, blocks);
+	const uint64_t vals = (uint64_t)pl->stream_values * pl->batch;
+	if (int rc = LA.end("requantize", 0, 0, vals, vals * 2, vals * 2))
+		return rc;
+	HIP_TRY(hipStreamSynchronize(pl->stream));  // the host table may go away
+	if (d_out)
+		*d_out = pl->d_requant;
+	return 0;
+}
+
+int akoHipRequantize(akoHipPlan* pl, int quantization, int gate, const void* d_unquantized, void** d_out)
+{
+	return guarded([&] { return requantize(pl, quantization, gate, d_unquantized, d_out); });
+}
+
 int akoHipKagariFetch(akoHipPlan* pl, void* h_body)
 {
 	if (!pl || !pl->kg || !h_body || pl->kg->body_bytes == 0)
@@ -1404,8 +1625,15 @@ const void* akoHipKagariBody(const akoHipPlan* pl)
 	return (pl && pl->kg && pl->kg->body_bytes) ? pl->kg->d_body : nullptr;
 }
 
+static int kagari_expand(akoHipPlan* pl, const int16_t* h_literals, size_t n_literals, const struct akoHipKagariRun* h_runs,
+                         size_t n_runs, void* d_streams, size_t image);
 int akoHipKagariExpand(akoHipPlan* pl, const int16_t* h_literals, size_t n_literals, const struct akoHipKagariRun* h_runs,
                        size_t n_runs, void* d_streams, size_t image)
+{
+	return guarded([&] { return kagari_expand(pl, h_literals, n_literals, h_runs, n_runs, d_streams, image); });
+}
+static int kagari_expand(akoHipPlan* pl, const int16_t* h_literals, size_t n_literals, const struct akoHipKagariRun* h_runs,
+                         size_t n_runs, void* d_streams, size_t image)
 {
 	static_assert(sizeof(KgRun) == sizeof(struct akoHipKagariRun), "record layout");
 	if (!pl || !h_literals || n_literals == 0 || (n_runs != 0 && !h_runs) || image >= pl->batch)

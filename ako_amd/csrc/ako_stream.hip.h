@@ -649,6 +649,87 @@ __device__ __forceinline__ void decode_pixels_pair(const uint32_t px[4], int col
 	}
 }
 
+// ---- 16-bit packing on the float pipe through SDWA conversions ------------------------------------
+// Two / four integer-valued floats inside the int16 range -> packed int16 pairs: v_cvt_i32_f32 writing straight
+// into the low / high word of the destination (dst_sel), instead of two full conversions + v_cvt_pk_i16_i32.
+// gfx940+ need one wait state between an instruction with dst_sel != DWORD and a VALU instruction that reads
+// its destination (here: the second conversion into the same register, which preserves the word the first one
+// wrote); compilers insert it for their own code, not inside inline assembly, so the conversions of TWO words
+// are interleaved and a trailing s_nop covers whatever VALU instruction comes next.
+__device__ __forceinline__ void pack2x2_f(float a_lo, float a_hi, float b_lo, float b_hi, uint32_t& a, uint32_t& b)
+{
+	asm("v_cvt_i32_f32_sdwa %0, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+	    "v_cvt_i32_f32_sdwa %1, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+	    "v_cvt_i32_f32_sdwa %0, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+	    "v_cvt_i32_f32_sdwa %1, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+	    "s_nop 0"
+	    : "=&v"(a), "=&v"(b)
+	    : "v"(a_lo), "v"(a_hi), "v"(b_lo), "v"(b_hi));
+}
+// a packed int16 pair -> two floats: sign-extending word selects on the source of the conversion
+__device__ __forceinline__ void unpack2_f(uint32_t w, float& lo, float& hi)
+{
+	asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(lo) : "v"(w));
+	asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(hi) : "v"(w));
+}
+
+// Gate as a factor on the float pipe: for integer-valued f and integer g, clamp(|f| - g, 0, 1) is exactly 1 where
+// |f| > g and exactly 0 elsewhere (one v_sub_f32 with the abs and clamp modifiers), so the gated, scaled value is
+// f * rq * that -- two plain multiplies instead of a compare and a select around the conversion.
+__device__ __forceinline__ float gate_scale_f(float f, float gf, float rq)
+{
+	const float open = __builtin_fminf(__builtin_fmaxf(__builtin_fabsf(f) - gf, 0.0f), 1.0f);
+	return (f * rq) * open;
+}
+
+// the row of one plane: LL pair + the three gated / quantized high-pass pairs -> four packed words
+__device__ __forceinline__ void pack_row_f(const float lp[4], const float hp[4], float gf, float rq, uint32_t& w_ll,
+                                           uint32_t& w_c, uint32_t& w_b, uint32_t& w_d)
+{
+	pack2x2_f(lp[0], lp[1], gate_scale_f(hp[0], gf, rq), gate_scale_f(hp[1], gf, rq), w_ll, w_c);
+	pack2x2_f(gate_scale_f(lp[2], gf, rq), gate_scale_f(lp[3], gf, rq), gate_scale_f(hp[2], gf, rq),
+	          gate_scale_f(hp[3], gf, rq), w_b, w_d);
+}
+__device__ __forceinline__ void pack_row_f(const int lp[4], const int hp[4], float gf, float rq, uint32_t& w_ll,
+                                           uint32_t& w_c, uint32_t& w_b, uint32_t& w_d)
+{
+	const float l2 = (float)lp[2], l3 = (float)lp[3];
+	const float h0 = (float)hp[0], h1 = (float)hp[1], h2 = (float)hp[2], h3 = (float)hp[3];
+	uint32_t unused;
+	w_ll = pack2_inrange(lp[0], lp[1]);
+	pack2x2_f(gate_scale_f(h0, gf, rq), gate_scale_f(h1, gf, rq), gate_scale_f(l2, gf, rq), gate_scale_f(l3, gf, rq), w_c, w_b);
+	pack2x2_f(gate_scale_f(h2, gf, rq), gate_scale_f(h3, gf, rq), 0.0f, 0.0f, w_d, unused);
+}
+
+// The common case of the u8 kernels spelled out: YCoCg / YCoCg_Q without the discard-transparent rule.  No colour
+// mode dispatch per row, and each wave of the pair converts only the three channels its two planes are made of
+// (Y and Cg: r, g, b; Co and alpha: r, b, a).
+template <typename V>
+__device__ __forceinline__ void decode_pixels_ycocg(const uint32_t px[4], V ymul, int pair, V v0[4], V v1[4])
+{
+	if (pair == 0)  // wave-uniform
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			const V r = (V)(px[k] & 255), g = (V)((px[k] >> 8) & 255), b = (V)((px[k] >> 16) & 255);
+			const V co = r - b;
+			const V t = b + half_trunc(co);
+			const V cg = g - t;
+			v0[k] = (t + half_trunc(cg)) * ymul, v1[k] = cg;
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			const V r = (V)(px[k] & 255), b = (V)((px[k] >> 16) & 255);
+			v0[k] = r - b, v1[k] = (V)(px[k] >> 24);
+		}
+	}
+}
+
 // gate + quantize on the float pipe (see quantize() in ako_kernels.hip.h for the exactness argument;
 // q == 1 needs no special case: trunc(v * fl(1 + 1e-6)) == v for |v| <= 32768)
 __device__ __forceinline__ int quantize_f(int v, float gf, float rq)
@@ -739,7 +820,13 @@ struct FwdRaw<false>
 	vec a[2];
 };
 
-template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE>
+// DEEP = 0: a wave prefetches two row slots ahead of the one it works on (ring of three).  DEEP = N > 0, for
+// segments of at most N - 6 rows: ALL N row slots of the segment are fetched before the first one is used.  Small
+// levels have too few waves to hide memory latency behind each other, and a wave's row slots are a dependent
+// chain: with the running prefetch every slot of such a wave waits for its own round trip to memory, with all
+// loads in flight at once the segment costs one round trip.  (A single pass over exactly N slots: the ring indices
+// of the column pipeline stay compile-time constants for any N.)
+template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE, int DEEP, bool CFAST = false>
 __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
                                                     const LaneCols& lc, int lane)
 {
@@ -793,13 +880,18 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(
 	    ll_root, 0, (int)(uint32_t)(ll_left < 0xFFFFFFFFull ? ll_left : 0xFFFFFFFFull), RSRC_FLAGS);
 	const uint32_t ll_pitch = P.ll_out_stream ? (uint32_t)Tc : P.dst_pitch;
-	uint32_t ll_off[NPL], grp_off[NPL];  // byte offsets of this lane's column pair in row 0
+	// Byte offsets of this lane's column pair in row 0: the per-lane part of a store address (voffset).  A lane that
+	// must not store carries an out-of-range one here, once and for all; the ROW part of the address is wave-uniform
+	// and travels as the scalar offset of the store, 0xFFFFFFFF for a row that must not be stored -- the hardware
+	// checks voffset + soffset (as a sum that does not wrap, scripts/probe_buffer_soffset.hip) against the end of
+	// the buffer.  No vector instruction is spent on addresses inside the row loop.
+	uint32_t ll_off[NPL], grp_off[NPL];
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 	{
 		const int pl = p_first + p * P_STEP;
-		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1 + c0) * 2);
-		ll_off[p] = (uint32_t)(((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) + c0) * 2);
+		grp_off[p] = store_lane ? (uint32_t)((P.grp_off[pl] + 1 + c0) * 2) : OOB;
+		ll_off[p] = store_lane ? (uint32_t)(((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) + c0) * 2) : OOB;
 	}
 	const uint32_t nsub_b = (uint32_t)(nsub * 2);
 
@@ -843,19 +935,9 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		for (int k = 0; k < 4 * NPL; k++)
 			__builtin_amdgcn_raw_buffer_store_b32(0u, rs_stream, OOB, 0, 0);
 	};
-	Raw ring[3];
-	fetch(v_begin, ring[0]);
-	phantom_stores();
-	fetch(v_begin + 1, ring[1]);
-	phantom_stores();
-
-	for (int base = 0; base < n_slots; base += 6)
-	{
-		static_for<6>([&](auto kc) {
+	// one row slot: K = unroll position (ring indices of the column pipeline), v = slot, raw = its two fetched rows
+	auto do_slot = [&](auto kc, const int v, const Raw& raw) {
 			constexpr int K = decltype(kc)::value;
-			const int v = v_begin + base + K;
-			fetch(v + 2, ring[(K + 2) % 3]);  // prefetch two slots ahead (clamped rows: always in range)
-			const Raw& raw = ring[K % 3];
 			const bool zero_row = VEDGE && (wrap == W_ZERO) && ((unsigned)v >= (unsigned)Tr);
 
 			V smp[2][NPL][4];
@@ -866,7 +948,10 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				{
 					const uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
 					V v0[4], v1[4];
-					decode_pixels_pair<V>(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
+					if constexpr (CFAST)
+						decode_pixels_ycocg<V>(px, (P.color == C_YCOCG_Q) ? (V)2 : (V)1, (int)id.pg, v0, v1);
+					else
+						decode_pixels_pair<V>(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 					{
@@ -912,30 +997,52 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
 				const float gf = (p_first + p * P_STEP == 0) ? gf_luma : gf_chroma;
 				const float rq = (p_first + p * P_STEP == 0) ? P.rq_luma : P.rq_chroma;
-				w_ll[p] = pack2_inrange(to_int(lp[0]), to_int(lp[1]));
-				w_c[p] = pack2_inrange(quantize_f(hp[0], gf, rq), quantize_f(hp[1], gf, rq));
-				w_b[p] = pack2_inrange(quantize_f(lp[2], gf, rq), quantize_f(lp[3], gf, rq));
-				w_d[p] = pack2_inrange(quantize_f(hp[2], gf, rq), quantize_f(hp[3], gf, rq));
+				pack_row_f(lp, hp, gf, rq, w_ll[p], w_c[p], w_b[p], w_d[p]);
 			}
 			{
-				const bool ok = store_lane && (r >= r_lo) && (r < r_hi);
+				const bool row_ok = (r >= r_lo) && (r < r_hi);  // wave-uniform
 				const uint32_t rr = (uint32_t)r;
-				const uint32_t row_grp = rr * (uint32_t)Tc * 2u, row_ll = rr * ll_pitch * 2u;
+				const uint32_t row_grp = row_ok ? rr * (uint32_t)Tc * 2u : OOB;
+				const uint32_t row_ll = row_ok ? rr * ll_pitch * 2u : OOB;
+				const uint32_t row_b = row_ok ? row_grp + nsub_b : OOB, row_d = row_ok ? row_grp + 2u * nsub_b : OOB;
 #pragma unroll
 				for (int p = 0; p < NPL; p++)
 				{
-					const uint32_t g0 = grp_off[p] + row_grp;
-					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, ok ? ll_off[p] + row_ll : OOB, 0, 0);
-					__builtin_amdgcn_raw_buffer_store_b32(w_c[p], rs_stream, ok ? g0 : OOB, 0, 0);
-					__builtin_amdgcn_raw_buffer_store_b32(w_b[p], rs_stream, ok ? g0 + nsub_b : OOB, 0, 0);
-					__builtin_amdgcn_raw_buffer_store_b32(w_d[p], rs_stream, ok ? g0 + 2u * nsub_b : OOB, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, ll_off[p], row_ll, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_c[p], rs_stream, grp_off[p], row_grp, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_b[p], rs_stream, grp_off[p], row_b, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_d[p], rs_stream, grp_off[p], row_d, 0);
 				}
 			}
-		});
+	};
+
+	if constexpr (DEEP > 0)
+	{
+		(void)n_slots, (void)phantom_stores;
+		Raw all[DEEP];
+		static_for<DEEP>([&](auto kc) { fetch(v_begin + decltype(kc)::value, all[decltype(kc)::value]); });
+		static_for<DEEP>([&](auto kc) { do_slot(kc, v_begin + decltype(kc)::value, all[decltype(kc)::value]); });
+	}
+	else
+	{
+		Raw ring[3];
+		fetch(v_begin, ring[0]);
+		phantom_stores();
+		fetch(v_begin + 1, ring[1]);
+		phantom_stores();
+		for (int base = 0; base < n_slots; base += 6)
+		{
+			static_for<6>([&](auto kc) {
+				constexpr int K = decltype(kc)::value;
+				const int v = v_begin + base + K;
+				fetch(v + 2, ring[(K + 2) % 3]);  // prefetch two slots ahead (clamped rows: always in range)
+				do_slot(kc, v, ring[K % 3]);
+			});
+		}
 	}
 }
 
-template <int KIND, int NPL, bool U8, bool NARROW>
+template <int KIND, int NPL, bool U8, bool NARROW, int DEEP = 0>
 __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P, const StreamGeom G)
 {
 	const UnitId id = decode_unit(P, G);
@@ -947,20 +1054,37 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 	const int r_lo = (int)id.seg * (int)G.seg_rows;
 	// (the unrolled row loop may run up to 5 slots past the segment and prefetches 2 further)
 	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
+	// u8 side: the usual colour mode gets straight-line pixel decoding (decode_pixels_ycocg)
+	const bool cfast = U8 && (P.color == C_YCOCG || P.color == C_YCOCG_Q) && P.discard == 0;
+#define AKO_FWD_BODY(H, V)                                                                       \
+	do                                                                                           \
+	{                                                                                            \
+		if constexpr (U8)                                                                        \
+		{                                                                                        \
+			if (cfast)                                                                           \
+				forward_stream_body<KIND, NPL, U8, NARROW, H, V, DEEP, true>(P, G, id, lc, lane);  \
+			else                                                                                 \
+				forward_stream_body<KIND, NPL, U8, NARROW, H, V, DEEP, false>(P, G, id, lc, lane); \
+		}                                                                                        \
+		else                                                                                     \
+			forward_stream_body<KIND, NPL, U8, NARROW, H, V, DEEP, false>(P, G, id, lc, lane);     \
+	} while (0)
+	(void)cfast;
 	if (lc.hedge)
 	{
 		if (vedge)
-			forward_stream_body<KIND, NPL, U8, NARROW, true, true>(P, G, id, lc, lane);
+			AKO_FWD_BODY(true, true);
 		else
-			forward_stream_body<KIND, NPL, U8, NARROW, true, false>(P, G, id, lc, lane);
+			AKO_FWD_BODY(true, false);
 	}
 	else
 	{
 		if (vedge)
-			forward_stream_body<KIND, NPL, U8, NARROW, false, true>(P, G, id, lc, lane);
+			AKO_FWD_BODY(false, true);
 		else
-			forward_stream_body<KIND, NPL, U8, NARROW, false, false>(P, G, id, lc, lane);
+			AKO_FWD_BODY(false, false);
 	}
+#undef AKO_FWD_BODY
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -989,7 +1113,7 @@ struct InvRaw
 constexpr float OPT_INPUT_BOUND = 3560.0f;
 constexpr float OPT_OUTPUT_BOUND = 10921.0f;
 
-template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE>
+template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE, int DEEP>
 __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
                                                     const LaneCols& lc, int lane, uint4 (*xbuf)[2][2][64])
 {
@@ -1074,17 +1198,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 
 	const int v_begin = r_lo - 3;
 	const int n_slots = r_hi + 3 - v_begin;
-	Raw ring[3];
-	fetch(v_begin, ring[0]);
-	fetch(v_begin + 1, ring[1]);
-
-	for (int base = 0; base < n_slots; base += 6)
-	{
-		static_for<6>([&](auto kc) {
+	auto do_slot = [&](auto kc, const int v, const Raw& raw) {
 			constexpr int K = decltype(kc)::value;
-			const int v = v_begin + base + K;
-			fetch(v + 2, ring[(K + 2) % 3]);
-			const Raw& raw = ring[K % 3];
 			const bool zero_row = VEDGE && (wrap == W_ZERO) && ((unsigned)v >= (unsigned)Tr);
 
 			const int r = v - 3;
@@ -1269,7 +1384,30 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 					}
 				}
 			}
-		});
+	};
+
+	if constexpr (DEEP > 0)
+	{
+		static_assert(!U8, "deep prefetch: int16 planes only (the u8 pair exchanges through LDS per slot)");
+		(void)n_slots;
+		Raw all[DEEP];
+		static_for<DEEP>([&](auto kc) { fetch(v_begin + decltype(kc)::value, all[decltype(kc)::value]); });
+		static_for<DEEP>([&](auto kc) { do_slot(kc, v_begin + decltype(kc)::value, all[decltype(kc)::value]); });
+	}
+	else
+	{
+		Raw ring[3];
+		fetch(v_begin, ring[0]);
+		fetch(v_begin + 1, ring[1]);
+		for (int base = 0; base < n_slots; base += 6)
+		{
+			static_for<6>([&](auto kc) {
+				constexpr int K = decltype(kc)::value;
+				const int v = v_begin + base + K;
+				fetch(v + 2, ring[(K + 2) % 3]);
+				do_slot(kc, v, ring[K % 3]);
+			});
+		}
 	}
 	if constexpr (OPT)
 	{
@@ -1279,7 +1417,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	}
 }
 
-template <int KIND, int NPL, bool U8, bool OPT>
+template <int KIND, int NPL, bool U8, bool OPT, int DEEP = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_inverse_stream(const LevelParams P, const StreamGeom G)
 {
 	__shared__ uint4 xbuf[2][2][2][64];  // U8 only: [slot parity][destination wave of the pair][plane][lane]
@@ -1299,16 +1437,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	if (lc.hedge)
 	{
 		if (vedge)
-			inverse_stream_body<KIND, NPL, U8, OPT, true, true>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, NPL, U8, OPT, true, true, DEEP>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, NPL, U8, OPT, true, false>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, NPL, U8, OPT, true, false, DEEP>(P, G, id, lc, lane, xbuf);
 	}
 	else
 	{
 		if (vedge)
-			inverse_stream_body<KIND, NPL, U8, OPT, false, true>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, NPL, U8, OPT, false, true, DEEP>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, NPL, U8, OPT, false, false>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, NPL, U8, OPT, false, false, DEEP>(P, G, id, lc, lane, xbuf);
 	}
 }
 

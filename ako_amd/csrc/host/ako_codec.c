@@ -48,11 +48,136 @@ struct plan_key
 	struct akoSettings s;
 	size_t channels, w, h;
 	int device;
+	uint64_t tuning; /* akoHipTuningSignature(): a plan created under other AKO_HIP_* knobs is not reused */
 };
 
-/* one slot per direction: an encoder's settings never equal a decoder's (quantization is not in the head) */
-static __thread akoHipPlan* cached_plans[2] = {NULL, NULL};
-static __thread struct plan_key cached_keys[2];
+/* one slot per direction: an encoder's settings never equal a decoder's (quantization is not in the head).
+ * The slots hang off a pthread key.  A thread that exits must hand its plans back -- device image and stream
+ * staging, entropy-stage buffers, scratch planes and an owned HIP stream, around 1 GB for an 8192x8192 RGBA plan,
+ * which a thread-per-request caller would otherwise leak once per thread -- but it cannot destroy them itself: by
+ * the time key destructors run, the HIP runtime's own per-thread state is gone and its calls no longer free
+ * anything reliably.  So the dying thread only PARKS its plans in a small process-wide pool (no HIP call); the next
+ * thread that needs a plan of the same shape takes it from there (a thread-per-request server keeps reusing the
+ * same few plans), and what does not fit in the pool is destroyed by the next live thread that enters the library. */
+struct plan_slots
+{
+	akoHipPlan* plans[2];
+	struct plan_key keys[2];
+};
+
+#define POOL_PLANS 8
+#define DOOMED_PLANS 64
+static pthread_mutex_t pool_mutex = PTHREAD_MUTEX_INITIALIZER;
+static struct
+{
+	akoHipPlan* plan;
+	struct plan_key key;
+	int slot;
+} pool[POOL_PLANS];
+static akoHipPlan* doomed[DOOMED_PLANS];
+static size_t n_doomed = 0;
+
+static pthread_key_t slots_key;
+static pthread_once_t slots_once = PTHREAD_ONCE_INIT;
+static int slots_key_ok = 0;
+
+/* thread exit: no HIP call in here */
+static void slots_park(void* arg)
+{
+	struct plan_slots* sl = arg;
+	if (sl == NULL)
+		return;
+	pthread_mutex_lock(&pool_mutex);
+	for (int k = 0; k < 2; k++)
+	{
+		if (sl->plans[k] == NULL)
+			continue;
+		int placed = 0;
+		for (int e = 0; e < POOL_PLANS && !placed; e++)
+			if (pool[e].plan == NULL)
+			{
+				pool[e].plan = sl->plans[k], pool[e].key = sl->keys[k], pool[e].slot = k;
+				placed = 1;
+			}
+		if (!placed && n_doomed < DOOMED_PLANS)
+			doomed[n_doomed++] = sl->plans[k], placed = 1;
+		/* (both full: the plan is lost to the process -- 72 parked plans mean nobody is coming back for them) */
+	}
+	pthread_mutex_unlock(&pool_mutex);
+	free(sl);
+}
+
+static void slots_make_key(void)
+{
+	slots_key_ok = (pthread_key_create(&slots_key, slots_park) == 0);
+}
+
+static struct plan_slots* thread_slots(int create)
+{
+	pthread_once(&slots_once, slots_make_key);
+	if (!slots_key_ok)
+		return NULL;
+	struct plan_slots* sl = pthread_getspecific(slots_key);
+	if (sl == NULL && create)
+	{
+		if ((sl = calloc(1, sizeof *sl)) == NULL)
+			return NULL;
+		if (pthread_setspecific(slots_key, sl) != 0)
+		{
+			free(sl);
+			return NULL;
+		}
+	}
+	return sl;
+}
+
+/* called by live threads: destroy what exited threads could not park */
+static void reap_doomed(void)
+{
+	if (__atomic_load_n(&n_doomed, __ATOMIC_RELAXED) == 0)
+		return;
+	akoHipPlan* mine[DOOMED_PLANS];
+	size_t n;
+	pthread_mutex_lock(&pool_mutex);
+	n = n_doomed;
+	memcpy(mine, doomed, n * sizeof mine[0]);
+	n_doomed = 0;
+	pthread_mutex_unlock(&pool_mutex);
+	for (size_t k = 0; k < n; k++)
+		akoHipPlanDestroy(mine[k]);
+}
+
+static akoHipPlan* pool_take(int slot, const struct plan_key* key)
+{
+	akoHipPlan* p = NULL;
+	pthread_mutex_lock(&pool_mutex);
+	for (int e = 0; e < POOL_PLANS && p == NULL; e++)
+		if (pool[e].plan != NULL && pool[e].slot == slot && memcmp(&pool[e].key, key, sizeof *key) == 0)
+			p = pool[e].plan, pool[e].plan = NULL;
+	pthread_mutex_unlock(&pool_mutex);
+	return p;
+}
+
+/* Explicit release: the calling thread's cached plans, and every plan parked by threads that have exited. */
+AKO_API void akoHipThreadRelease(void)
+{
+	struct plan_slots* sl = thread_slots(0);
+	for (int k = 0; sl != NULL && k < 2; k++)
+		if (sl->plans[k] != NULL)
+		{
+			akoHipPlanDestroy(sl->plans[k]);
+			sl->plans[k] = NULL;
+		}
+	akoHipPlan* parked[POOL_PLANS];
+	pthread_mutex_lock(&pool_mutex);
+	for (int e = 0; e < POOL_PLANS; e++)
+		parked[e] = pool[e].plan, pool[e].plan = NULL;
+	pthread_mutex_unlock(&pool_mutex);
+	for (int e = 0; e < POOL_PLANS; e++)
+		if (parked[e] != NULL)
+			akoHipPlanDestroy(parked[e]);
+	reap_doomed();
+}
 
 static int plan_cache_on(void)
 {
@@ -69,16 +194,26 @@ static akoHipPlan* plan_acquire(int slot, const struct akoSettings* st, size_t c
 	key.s.tiles_dimension = st->tiles_dimension, key.s.quantization = st->quantization, key.s.gate = st->gate;
 	key.s.chroma_loss = st->chroma_loss, key.s.discard_non_visible = st->discard_non_visible;
 	key.channels = channels, key.w = w, key.h = h, key.device = chosen_device();
+	key.tuning = akoHipTuningSignature();
 
-	if (cached_plans[slot] != NULL)
+	reap_doomed();
+	struct plan_slots* sl = thread_slots(1);
+	if (sl != NULL && sl->plans[slot] != NULL)
 	{
-		akoHipPlan* p = cached_plans[slot];
-		cached_plans[slot] = NULL; /* taken out while in use: an event callback may call back into the library */
-		if (plan_cache_on() && memcmp(&key, &cached_keys[slot], sizeof key) == 0)
+		akoHipPlan* p = sl->plans[slot];
+		sl->plans[slot] = NULL; /* taken out while in use: an event callback may call back into the library */
+		if (plan_cache_on() && memcmp(&key, &sl->keys[slot], sizeof key) == 0)
 			return p;
 		akoHipPlanDestroy(p);
 	}
-	cached_keys[slot] = key;
+	if (sl != NULL)
+		sl->keys[slot] = key;
+	if (plan_cache_on())
+	{
+		akoHipPlan* parked = pool_take(slot, &key); /* left behind by a thread that has exited */
+		if (parked != NULL)
+			return parked;
+	}
 	/* an own stream per plan: calls from different host threads overlap on the GPU instead of queueing up on
 	 * the legacy default stream (every driver call below ends with a synchronisation of that stream) */
 	return akoHipPlanCreate(key.device, st, channels, w, h, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, status);
@@ -88,8 +223,9 @@ static void plan_release(int slot, akoHipPlan* plan, int healthy)
 {
 	if (plan == NULL)
 		return;
-	if (healthy && plan_cache_on() && cached_plans[slot] == NULL)
-		cached_plans[slot] = plan; /* its key was stored by plan_acquire */
+	struct plan_slots* sl = thread_slots(0);
+	if (healthy && plan_cache_on() && sl != NULL && sl->plans[slot] == NULL)
+		sl->plans[slot] = plan; /* its key was stored by plan_acquire */
 	else
 		akoHipPlanDestroy(plan);
 }
@@ -126,15 +262,25 @@ static void* tile_worker(void* arg)
 	}
 }
 
+static size_t tokenize_workers(void)
+{
+	long cores = sysconf(_SC_NPROCESSORS_ONLN);
+	size_t workers = (cores > 1) ? (size_t)cores : 1;
+	return workers > 16 ? 16 : workers;
+}
+
 static void tokenize_tiles(struct tile_job* jobs, size_t count)
 {
 	struct tile_pool pool = {jobs, count, 0};
-	long cores = sysconf(_SC_NPROCESSORS_ONLN);
-	size_t workers = (cores > 1) ? (size_t)cores : 1;
-	if (workers > 16)
-		workers = 16;
+	size_t workers = tokenize_workers();
 	if (workers > count)
 		workers = count;
+	/* threads only where they pay: a window of small tiles is parsed faster than a thread starts */
+	size_t payload = 0;
+	for (size_t k = 0; k < count; k++)
+		payload += jobs[k].block;
+	if (payload < 64 * 1024)
+		workers = 1;
 	pthread_t th[16];
 	size_t started = 0;
 	for (size_t k = 1; k < workers; k++) /* the calling thread is worker 0 */
@@ -143,6 +289,117 @@ static void tokenize_tiles(struct tile_job* jobs, size_t count)
 	tile_worker(&pool);
 	for (size_t k = 0; k < started; k++)
 		pthread_join(th[k], NULL);
+}
+
+/* ---- several devices: a tiled image split into bands of whole tile rows -------------------------------------
+ * Tiles are independent and stored in raster order (library/encode.c:115-205), so a band of whole tile rows is
+ * itself a valid image whose stream -- and whose blob body -- is exactly that slice of the whole image's.  With
+ * AKO_HIP_DEVICES naming more than one device ("all", or a list such as "0,1,2,3"; a device may be named twice)
+ * akoEncodeExt / akoDecodeExt give every device one band (own plan, own stream, a worker thread of the library
+ * each) and join the bodies in band order on the calling thread.  No data moves between devices. */
+#define MAX_BANDS 16
+
+static size_t device_list(int* devs, size_t max)
+{
+	const char* e = getenv("AKO_HIP_DEVICES");
+	if (e == NULL || *e == '\0')
+		return 0;
+	size_t n = 0;
+	if (strcmp(e, "all") == 0)
+	{
+		const int count = akoHipDeviceCount();
+		for (int d = 0; d < count && n < max; d++)
+			devs[n++] = d;
+		return n;
+	}
+	while (*e != '\0' && n < max)
+	{
+		char* stop = NULL;
+		const long v = strtol(e, &stop, 10);
+		if (stop == e)
+			break;
+		devs[n++] = (int)v;
+		e = (*stop == ',') ? stop + 1 : stop;
+	}
+	return n;
+}
+
+struct band
+{
+	int device, decode;
+	struct akoSettings st;
+	size_t channels, w, y0, rows;
+	akoHipPlan* plan;
+	const uint8_t* pixels_in; /* encode */
+	uint8_t* body_out;
+	size_t body_out_bytes;
+	const uint8_t* body_in;   /* decode */
+	size_t body_in_bytes;
+	uint8_t* pixels_out;
+	enum akoStatus status;
+	pthread_t thread;
+	int started;
+};
+
+static void* band_main(void* arg)
+{
+	struct band* b = arg;
+	if (b->plan == NULL)
+		b->plan = akoHipPlanCreate(b->device, &b->st, b->channels, b->w, b->rows, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &b->status);
+	if (b->plan == NULL)
+		return NULL;
+	if (b->decode)
+		b->status = akoHostDecodeBody(b->plan, b->st.compression, b->body_in, b->body_in_bytes, NULL, b->pixels_out);
+	else
+		b->status = akoHostEncodeBody(b->plan, b->st.compression, b->pixels_in, 0, &b->body_out, &b->body_out_bytes);
+	return NULL;
+}
+
+/* bands[0 .. n) filled in by the caller; runs them (band 0 on the calling thread) and returns the first failure */
+static enum akoStatus run_bands(struct band* bands, size_t n)
+{
+	for (size_t k = 1; k < n; k++)
+		bands[k].started = (pthread_create(&bands[k].thread, NULL, band_main, &bands[k]) == 0);
+	band_main(&bands[0]);
+	for (size_t k = 1; k < n; k++)
+	{
+		if (bands[k].started)
+			pthread_join(bands[k].thread, NULL);
+		else
+			band_main(&bands[k]);
+	}
+	enum akoStatus st = AKO_OK;
+	for (size_t k = 0; k < n; k++)
+	{
+		if (bands[k].plan != NULL)
+			akoHipPlanDestroy(bands[k].plan);
+		bands[k].plan = NULL;
+		if (st == AKO_OK && bands[k].status != AKO_OK)
+			st = bands[k].status;
+	}
+	return st;
+}
+
+/* how a tiled image of `h` rows is cut: n bands of whole tile rows, as equal as they come */
+static size_t cut_bands(size_t h, size_t td, size_t n_devices, size_t* y0, size_t* rows)
+{
+	const size_t tile_rows = (h + td - 1) / td;
+	size_t n = n_devices < tile_rows ? n_devices : tile_rows;
+	if (n > MAX_BANDS)
+		n = MAX_BANDS;
+	const size_t per = (tile_rows + n - 1) / n;
+	size_t used = 0;
+	for (size_t k = 0; k < n; k++)
+	{
+		const size_t first = k * per;
+		if (first >= tile_rows)
+			break;
+		const size_t last = (first + per < tile_rows) ? first + per : tile_rows;
+		y0[used] = first * td;
+		rows[used] = ((last * td < h) ? last * td : h) - first * td;
+		used++;
+	}
+	return used;
 }
 
 static void complain(const char* where)
@@ -187,6 +444,70 @@ AKO_API size_t akoEncodeExt(const struct akoCallbacks* c, const struct akoSettin
 	}
 	if ((status = akoHostHeadWrite(channels, image_w, image_h, &st, blob)) != AKO_OK)
 		goto failure;
+
+	/* several devices (AKO_HIP_DEVICES) and a tiled image of two tile rows or more: one band per device */
+	{
+		int devs[MAX_BANDS];
+		const size_t nd = device_list(devs, MAX_BANDS);
+		const size_t td = st.tiles_dimension;
+		if (nd > 1 && td != 0 && image_h > td)
+		{
+			struct band bands[MAX_BANDS];
+			size_t y0[MAX_BANDS], rows[MAX_BANDS];
+			memset(bands, 0, sizeof bands);
+			const size_t nb = cut_bands(image_h, td, nd, y0, rows);
+			const size_t tiles_all = ((image_w + td - 1) / td) * ((image_h + td - 1) / td);
+			for (size_t k = 0; k < nb; k++)
+			{
+				bands[k].device = devs[k], bands[k].st = st, bands[k].channels = channels, bands[k].w = image_w;
+				bands[k].y0 = y0[k], bands[k].rows = rows[k];
+				bands[k].pixels_in = (const uint8_t*)in + y0[k] * image_w * channels;
+			}
+			/* the reference's event sequence, per tile in order (encode.c:132-184); all device work sits in tile 0's
+			 * WAVELET bracket, as in the single-device driver */
+			for (size_t t = 0; t < tiles_all; t++)
+			{
+				fire(&cb, t, tiles_all, AKO_EVENT_FORMAT_START);
+				fire(&cb, t, tiles_all, AKO_EVENT_FORMAT_END);
+				if (st.wavelet != AKO_WAVELET_NONE)
+					fire(&cb, t, tiles_all, AKO_EVENT_WAVELET_START);
+				if (t == 0 && (status = run_bands(bands, nb)) != AKO_OK)
+				{
+					if (status != AKO_ERROR)
+						complain("akoEncodeExt (bands)");
+					for (size_t k = 0; k < nb; k++)
+						free(bands[k].body_out);
+					goto failure;
+				}
+				if (st.wavelet != AKO_WAVELET_NONE)
+					fire(&cb, t, tiles_all, AKO_EVENT_WAVELET_END);
+				fire(&cb, t, tiles_all, AKO_EVENT_COMPRESSION_START);
+				if (t == 0)
+				{
+					size_t total = 0;
+					for (size_t k = 0; k < nb; k++)
+						total += bands[k].body_out_bytes;
+					uint8_t* grown = cb.realloc(blob, blob_size + total);
+					if (grown == NULL)
+					{
+						for (size_t k = 0; k < nb; k++)
+							free(bands[k].body_out);
+						status = AKO_NO_ENOUGH_MEMORY;
+						goto failure;
+					}
+					blob = grown;
+					for (size_t k = 0; k < nb; k++)
+					{
+						memcpy(blob + blob_size, bands[k].body_out, bands[k].body_out_bytes);
+						blob_size += bands[k].body_out_bytes;
+						free(bands[k].body_out);
+					}
+				}
+				fire(&cb, t, tiles_all, AKO_EVENT_COMPRESSION_END);
+			}
+			goto done;
+		}
+	}
 
 	if ((plan = plan_acquire(0, &st, channels, image_w, image_h, &status)) == NULL)
 	{
@@ -411,6 +732,125 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	if ((status = akoHostHeadRead(input, &channels, &image_w, &image_h, &st)) != AKO_OK)
 		goto failure;
 
+	/* The head is untrusted: before anything is sized from it, it must be able to describe this blob.  Every tile
+	 * costs at least 5 bytes under Kagari (block size + one payload byte) and its whole stream (>= 2 bytes per
+	 * sample) without compression; products that leave 64 bits are not an image.  (A forged 16 byte blob claiming
+	 * 2^32 x 2^32 pixels in 8 pixel tiles would otherwise ask for ~10^17 tile records.) */
+	{
+		const size_t td = st.tiles_dimension;
+		const size_t tiles_x = (td != 0) ? (image_w + td - 1) / td : 1;
+		const size_t tiles_y = (td != 0) ? (image_h + td - 1) / td : 1;
+		size_t n_tiles = 0, samples = 0, raw_bytes = 0, need = 0;
+		if (__builtin_mul_overflow(tiles_x, tiles_y, &n_tiles) || __builtin_mul_overflow(image_w, image_h, &samples) ||
+		    __builtin_mul_overflow(samples, channels, &samples) || __builtin_mul_overflow(samples, (size_t)2, &raw_bytes) ||
+		    raw_bytes > ((size_t)1 << 46))
+		{
+			status = AKO_NO_ENOUGH_MEMORY;
+			goto failure;
+		}
+		if (st.compression != AKO_COMPRESSION_NONE)
+		{
+			if (__builtin_mul_overflow(n_tiles, (size_t)5, &need))
+				need = (size_t)-1;
+		}
+		else
+			need = raw_bytes;
+		if (input_size - sizeof(struct akoHead) < need)
+		{
+			status = AKO_BROKEN_INPUT;
+			goto failure;
+		}
+	}
+
+	/* several devices (AKO_HIP_DEVICES) and a tiled image of two tile rows or more: one band per device */
+	{
+		int devs[MAX_BANDS];
+		const size_t nd = device_list(devs, MAX_BANDS);
+		const size_t td = st.tiles_dimension;
+		if (nd > 1 && td != 0 && image_h > td)
+		{
+			struct band bands[MAX_BANDS];
+			size_t y0[MAX_BANDS], rows[MAX_BANDS];
+			memset(bands, 0, sizeof bands);
+			const size_t nb = cut_bands(image_h, td, nd, y0, rows);
+			const size_t tiles_x = (image_w + td - 1) / td;
+			const size_t tiles_all = tiles_x * ((image_h + td - 1) / td);
+			if ((image = cb.malloc(image_w * image_h * channels)) == NULL)
+			{
+				status = AKO_NO_ENOUGH_MEMORY;
+				goto failure;
+			}
+			/* where every band's body starts: fixed stream sizes without compression, the chain of block sizes with */
+			const uint8_t* at = (const uint8_t*)input + sizeof(struct akoHead);
+			const uint8_t* const stop = (const uint8_t*)input + input_size;
+			for (size_t k = 0; k < nb && status == AKO_OK; k++)
+			{
+				struct band* b = &bands[k];
+				b->device = devs[k], b->decode = 1, b->st = st, b->channels = channels, b->w = image_w;
+				b->y0 = y0[k], b->rows = rows[k];
+				b->pixels_out = image + y0[k] * image_w * channels;
+				b->body_in = at;
+				if (st.compression == AKO_COMPRESSION_NONE)
+				{
+					/* plans are created here, one after the other, for the sizes of their streams */
+					if ((b->plan = akoHipPlanCreate(b->device, &st, channels, image_w, rows[k], 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &status)) == NULL)
+						break;
+					const size_t need = akoHipPlanStreamBytes(b->plan);
+					if ((size_t)(stop - at) < need)
+						status = AKO_BROKEN_INPUT;
+					else
+						at += need;
+				}
+				else
+				{
+					const size_t band_tiles = tiles_x * ((rows[k] + td - 1) / td);
+					for (size_t t = 0; t < band_tiles; t++)
+					{
+						uint32_t block = 0;
+						if ((size_t)(stop - at) < 4)
+						{
+							status = AKO_BROKEN_INPUT;
+							break;
+						}
+						memcpy(&block, at, 4);
+						if ((size_t)(stop - at) - 4 < block)
+						{
+							status = AKO_BROKEN_INPUT;
+							break;
+						}
+						at += (size_t)block + 4;
+					}
+				}
+				b->body_in_bytes = (size_t)(at - b->body_in);
+			}
+			if (status == AKO_OK)
+				status = run_bands(bands, nb);
+			else
+				for (size_t k = 0; k < nb; k++)
+					if (bands[k].plan != NULL)
+						akoHipPlanDestroy(bands[k].plan);
+			if (status != AKO_OK)
+			{
+				if (status != AKO_BROKEN_INPUT)
+					complain("akoDecodeExt (bands)");
+				goto failure;
+			}
+			for (size_t t = 0; t < tiles_all; t++) /* decode.c:145-207 */
+			{
+				fire(&cb, t, tiles_all, AKO_EVENT_COMPRESSION_START);
+				fire(&cb, t, tiles_all, AKO_EVENT_COMPRESSION_END);
+				if (st.wavelet != AKO_WAVELET_NONE)
+				{
+					fire(&cb, t, tiles_all, AKO_EVENT_WAVELET_START);
+					fire(&cb, t, tiles_all, AKO_EVENT_WAVELET_END);
+				}
+				fire(&cb, t, tiles_all, AKO_EVENT_FORMAT_START);
+				fire(&cb, t, tiles_all, AKO_EVENT_FORMAT_END);
+			}
+			goto decoded;
+		}
+	}
+
 	if ((plan = plan_acquire(1, &st, channels, image_w, image_h, &status)) == NULL)
 	{
 		complain("akoDecodeExt");
@@ -435,31 +875,21 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 		}
 		memset(&tokens, 0, sizeof tokens);
 
-		/* several tiles: walk the chain of block sizes, then parse all tiles at once on worker threads */
+		/* several tiles: they are parsed on worker threads, a bounded WINDOW of tiles at a time (host memory stays
+		 * proportional to the window, not to the tile count: an 8192x8192 image in 8 pixel tiles has a million),
+		 * and merged in tile order as the loop below reaches them */
+		const uint8_t* walk = cursor; /* runs ahead of `cursor` along the chain of block sizes */
+		size_t win_first = 0, win_count = 0;
 		if (tiles > 1)
 		{
-			if ((jobs = calloc(tiles, sizeof *jobs)) == NULL)
+			n_jobs = tokenize_workers() * 8;
+			if (n_jobs > tiles)
+				n_jobs = tiles;
+			if ((jobs = calloc(n_jobs, sizeof *jobs)) == NULL)
 			{
 				status = AKO_NO_ENOUGH_MEMORY;
 				goto failure;
 			}
-			n_jobs = tiles;
-			const uint8_t* walk = cursor;
-			for (size_t t = 0; t < tiles; t++)
-			{
-				size_t off = 0, bytes = 0;
-				akoHipPlanTileInfo(plan, t, NULL, NULL, NULL, NULL, &off, &bytes);
-				uint32_t block = 0;
-				if ((size_t)(end - walk) < 4)
-					break; /* this tile and every later one keep payload == NULL */
-				memcpy(&block, walk, 4);
-				if ((size_t)(end - walk) - 4 < block)
-					break;
-				jobs[t].payload = walk + 4, jobs[t].block = block;
-				jobs[t].values = bytes / 2, jobs[t].out_base = off / 2;
-				walk += (size_t)block + 4;
-			}
-			tokenize_tiles(jobs, tiles);
 		}
 
 		for (size_t t = 0; t < tiles; t++)
@@ -480,10 +910,38 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 				status = AKO_BROKEN_INPUT;
 				goto failure;
 			}
+			if (jobs != NULL && t == win_first + win_count)
+			{
+				/* next window: walk the chain of block sizes, then parse its tiles at once */
+				win_first = t;
+				win_count = (tiles - t < n_jobs) ? tiles - t : n_jobs;
+				for (size_t k = 0; k < win_count; k++)
+				{
+					size_t o = 0, b = 0;
+					akoHipPlanTileInfo(plan, t + k, NULL, NULL, NULL, NULL, &o, &b);
+					memset(&jobs[k], 0, sizeof jobs[k]); /* payload == NULL: the chain ran off the input before this tile */
+					uint32_t blk = 0;
+					if (walk == NULL || (size_t)(end - walk) < 4)
+					{
+						walk = NULL;
+						continue;
+					}
+					memcpy(&blk, walk, 4);
+					if ((size_t)(end - walk) - 4 < blk)
+					{
+						walk = NULL;
+						continue;
+					}
+					jobs[k].payload = walk + 4, jobs[k].block = blk;
+					jobs[k].values = b / 2, jobs[k].out_base = o / 2;
+					walk += (size_t)blk + 4;
+				}
+				tokenize_tiles(jobs, win_count);
+			}
 			if (jobs != NULL)
 			{
 				/* merge this tile's list: literals are appended, 'after' counts become global */
-				struct tile_job* j = &jobs[t];
+				struct tile_job* j = &jobs[t - win_first];
 				if (j->used == 0 || j->used != block) /* compression.c:69-70 */
 				{
 					status = AKO_BROKEN_INPUT;
@@ -647,4 +1105,219 @@ failure:
 	if (out_status != NULL)
 		*out_status = status;
 	return NULL;
+}
+
+/* ---- ratio search in one call ---------------------------------------------------------------
+ * tools/akoenc.cpp:112-217 looks for the quantization that lands near ratio:1 by encoding the image again and again:
+ * quantization 0 for the upper bracket, then x4 steps until the blob is small enough, then bisection, then once more
+ * with the winner.  Every one of those encodes uploads the same pixels and runs the same lifting; only the stores of
+ * the C / B / D sub-bands and the lift heads depend on the quantization (library/lifting.c:154-168,253-267).  Here the
+ * pixels are uploaded once and transformed once per colour transformation (quantization 0 with gate 0 keeps plain
+ * YCoCg, every other candidate runs YCoCg_Q: library/encode.c:59-64 -- two transforms at most, one when the colour does
+ * not depend on it); a candidate then costs a pass over the unquantized coefficients (akoHipRequantize) and the
+ * device entropy stage, and only the winner's body crosses the link.  Control flow and arithmetic of the search are
+ * the reference's, so it settles on the same quantization and the blob is the one repeated akoEncodeExt calls give. */
+struct ratio_state
+{
+	akoHipPlan* plan_q;    /* colour of the candidates with quantization > 0 (or gate > 0); settings q = 0, g = 0 */
+	akoHipPlan* plan_0;    /* colour of the quantization 0 candidate when that differs, else NULL */
+	struct akoSettings base;
+	int have_q, have_0;    /* unquantized streams present on the device */
+	const void* pixels;
+	int encodes, transforms;
+	enum akoStatus status;
+};
+
+/* size of the blob for `quantization`, 0 when it fails (a tile that does not shrink: encode.c:159-164); the body
+ * stays on the device, in the entropy stage of the plan that is returned through *used */
+static size_t ratio_candidate(struct ratio_state* rs, int quantization, akoHipPlan** used)
+{
+	struct akoSettings s = rs->base;
+	s.quantization = quantization;
+	/* plan_0 exists only where quantization 0 (with the caller's gate) keeps another colour than the rest */
+	akoHipPlan* plan = (rs->plan_0 != NULL && quantization <= 0) ? rs->plan_0 : rs->plan_q;
+	int* have = (plan == rs->plan_0) ? &rs->have_0 : &rs->have_q;
+	rs->encodes++;
+	int rc = 0;
+	if (!*have)
+	{
+		/* pixels go up once: the second plan transforms the first plan's device copy */
+		if (rs->have_q || rs->have_0)
+		{
+			akoHipPlan* other = (plan == rs->plan_0) ? rs->plan_q : rs->plan_0;
+			void* d_img = akoHipPlanDeviceImages(other);
+			void* d_str = akoHipPlanDeviceStreams(plan);
+			rc = (d_img != NULL && d_str != NULL) ? akoHipEncode(plan, d_img, d_str) : (int)AKO_NO_ENOUGH_MEMORY;
+		}
+		else
+			rc = akoHipEncodeUpload(plan, rs->pixels);
+		if (rc == 0)
+			rc = akoHipSynchronize(plan);
+		if (rc != 0)
+		{
+			rs->status = (enum akoStatus)rc;
+			return 0;
+		}
+		*have = 1;
+		rs->transforms++;
+	}
+	void* d_q = NULL;
+	size_t body = 0, bad = 0;
+	if ((rc = akoHipRequantize(plan, quantization, s.gate, NULL, &d_q)) == 0)
+		rc = akoHipKagariEncode(plan, d_q, 0, &body, &bad);
+	if (rc != 0)
+	{
+		rs->status = (enum akoStatus)rc; /* AKO_ERROR: did not shrink -- the search goes on with size 0, as the tool's does */
+		return 0;
+	}
+	rs->status = AKO_OK;
+	*used = plan;
+	return sizeof(struct akoHead) + body;
+}
+
+AKO_API size_t akoEncodeRatioExt(const struct akoCallbacks* c, const struct akoSettings* s, size_t channels, size_t image_w,
+                                 size_t image_h, const void* in, int ratio, void** out, int* out_quantization,
+                                 int* out_encodes, int* out_transforms, enum akoStatus* out_status)
+{
+	const struct akoCallbacks cb = (c != NULL) ? *c : akoDefaultCallbacks();
+	struct akoSettings base = (s != NULL) ? *s : akoDefaultSettings();
+	if (out_encodes != NULL)
+		*out_encodes = 1;
+	if (out_transforms != NULL)
+		*out_transforms = 1;
+	/* what the tool does without a search (tools/akoenc.cpp:116-128) */
+	if (ratio <= 1 || base.wavelet == AKO_WAVELET_NONE || base.compression == AKO_COMPRESSION_NONE)
+	{
+		if (ratio == 1)
+			base.quantization = 0, base.gate = 0; /* lossless */
+		if (out_quantization != NULL)
+			*out_quantization = base.quantization;
+		return akoEncodeExt(c, &base, channels, image_w, image_h, in, out, out_status);
+	}
+
+	enum akoStatus status = AKO_OK;
+	uint8_t* blob = NULL;
+	struct ratio_state rs;
+	memset(&rs, 0, sizeof rs);
+	rs.base = base, rs.pixels = in;
+	if (cb.malloc == NULL || cb.realloc == NULL || cb.free == NULL)
+	{
+		status = AKO_INVALID_CALLBACKS;
+		goto failure;
+	}
+	if (in == NULL)
+	{
+		status = AKO_INVALID_INPUT;
+		goto failure;
+	}
+	{
+		uint8_t head[sizeof(struct akoHead)]; /* validation as in the encoder (head.c:34-64) */
+		struct akoSettings probe = base;
+		probe.color = akoHipEffectiveColor(&probe);
+		if ((status = akoHostHeadWrite(channels, image_w, image_h, &probe, head)) != AKO_OK)
+			goto failure;
+	}
+	{
+		/* the unquantized plans: quantization 0, gate 0, colour fixed to what the candidates will have */
+		struct akoSettings u = base;
+		u.quantization = 1;
+		const enum akoColor color_q = akoHipEffectiveColor(&u);
+		u.quantization = 0;
+		const enum akoColor color_0 = akoHipEffectiveColor(&u); /* with the caller's gate */
+		u.gate = 0;
+		u.color = color_q;
+		if ((rs.plan_q = akoHipPlanCreate(chosen_device(), &u, channels, image_w, image_h, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &status)) == NULL)
+			goto failure;
+		if (color_0 != color_q)
+		{
+			u.color = color_0;
+			if ((rs.plan_0 = akoHipPlanCreate(chosen_device(), &u, channels, image_w, image_h, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &status)) == NULL)
+				goto failure;
+		}
+	}
+
+	/* ---- the search, step for step (tools/akoenc.cpp:130-214) ---- */
+	const size_t target = (image_w * image_h * channels) / (size_t)ratio;
+	const size_t margin = (target * 4) / 100;
+	akoHipPlan* last_plan = NULL;
+	int q = 0;
+	size_t ceil_size = ratio_candidate(&rs, 0, &last_plan), floor_size = ceil_size;
+	int ceil_q = 0, floor_q = 0;
+	q = 1;
+	do
+	{
+		q *= 4;
+		ceil_size = floor_size, ceil_q = floor_q;
+		floor_size = ratio_candidate(&rs, q, &last_plan), floor_q = q;
+	} while (floor_size > target && q < (1 << 28));
+
+	size_t last_size = floor_size;
+	int last_q = floor_q;
+#define DISTANCE(a, b) ((a) > (b) ? (a) - (b) : (b) - (a))
+	while (DISTANCE(floor_size, ceil_size) > margin && abs(floor_q - ceil_q) > 1)
+	{
+		q = (ceil_q + floor_q) / 2;
+		last_size = ratio_candidate(&rs, q, &last_plan), last_q = q;
+		if (last_size > target)
+			ceil_size = last_size, ceil_q = q;
+		else
+			floor_size = last_size, floor_q = q;
+	}
+	const int take_floor = DISTANCE(floor_size, target) < DISTANCE(ceil_size, target);
+#undef DISTANCE
+	const int best_q = take_floor ? floor_q : ceil_q;
+	const size_t best_size = take_floor ? floor_size : ceil_size;
+	/* tools/akoenc.cpp:207-213: the last encode is kept when its SIZE is the winner's (whatever its quantization) */
+	if (last_size != best_size)
+		last_size = ratio_candidate(&rs, best_q, &last_plan), last_q = best_q;
+	if (last_size == 0 || last_plan == NULL)
+	{
+		status = (rs.status != AKO_OK) ? rs.status : AKO_ERROR;
+		goto failure;
+	}
+
+	/* the winner: head + body out of the entropy stage */
+	if ((blob = cb.malloc(last_size)) == NULL)
+	{
+		status = AKO_NO_ENOUGH_MEMORY;
+		goto failure;
+	}
+	{
+		struct akoSettings fin = base;
+		fin.quantization = last_q;
+		fin.color = akoHipEffectiveColor(&fin);
+		if ((status = akoHostHeadWrite(channels, image_w, image_h, &fin, blob)) != AKO_OK)
+			goto failure;
+		if ((status = (enum akoStatus)akoHipKagariFetch(last_plan, blob + sizeof(struct akoHead))) != AKO_OK)
+			goto failure;
+	}
+	akoHipPlanDestroy(rs.plan_q);
+	if (rs.plan_0 != NULL)
+		akoHipPlanDestroy(rs.plan_0);
+	if (out_quantization != NULL)
+		*out_quantization = last_q;
+	if (out_encodes != NULL)
+		*out_encodes = rs.encodes;
+	if (out_transforms != NULL)
+		*out_transforms = rs.transforms;
+	if (out_status != NULL)
+		*out_status = AKO_OK;
+	if (out != NULL)
+		*out = blob;
+	else
+		cb.free(blob);
+	return last_size;
+
+failure:
+	if (status != AKO_ERROR && status != AKO_INVALID_INPUT && status != AKO_INVALID_CALLBACKS)
+		complain("akoEncodeRatioExt");
+	if (rs.plan_q != NULL)
+		akoHipPlanDestroy(rs.plan_q);
+	if (rs.plan_0 != NULL)
+		akoHipPlanDestroy(rs.plan_0);
+	if (blob != NULL && cb.free != NULL)
+		cb.free(blob);
+	if (out_status != NULL)
+		*out_status = status;
+	return 0;
 }

@@ -51,6 +51,13 @@ AKO_API int akoHostKagariTokensAppend(struct akoKagariTokens* dst, const struct 
                                       uint32_t literal_base);
 AKO_API void akoHostKagariTokensFree(struct akoKagariTokens* tok);
 
+/* ako_batch.c: one image (or band of tile rows) through a plan, host pixels <-> blob body (shared by the batch lanes
+ * and the multi-device route of akoEncodeExt / akoDecodeExt) */
+enum akoStatus akoHostEncodeBody(akoHipPlan* plan, enum akoCompression compression, const void* pixels, size_t head_room,
+                                 uint8_t** out, size_t* out_bytes);
+enum akoStatus akoHostDecodeBody(akoHipPlan* plan, enum akoCompression compression, const uint8_t* body, size_t body_bytes,
+                                 size_t* used, void* pixels);
+
 /* ako_synth.c: synthetic benchmark inputs */
 AKO_API void akoHostSynthImage(int generator, uint32_t seed, size_t w, size_t h, uint8_t* rgba);
 AKO_API void akoHostSynthPlane(uint32_t seed, size_t n, int16_t* plane);

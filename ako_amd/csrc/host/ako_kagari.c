@@ -236,7 +236,7 @@ static int tokens_reserve(struct akoKagariTokens* tok, size_t literals, size_t r
 {
 	if (tok->n_literals + literals > tok->cap_literals)
 	{
-		size_t cap = tok->cap_literals ? tok->cap_literals * 2 : 4096;
+		size_t cap = tok->cap_literals ? tok->cap_literals * 2 : 256;
 		while (cap < tok->n_literals + literals)
 			cap *= 2;
 		int16_t* p = realloc(tok->literals, cap * sizeof(int16_t));
@@ -246,7 +246,7 @@ static int tokens_reserve(struct akoKagariTokens* tok, size_t literals, size_t r
 	}
 	if (tok->n_runs + runs > tok->cap_runs)
 	{
-		size_t cap = tok->cap_runs ? tok->cap_runs * 2 : 1024;
+		size_t cap = tok->cap_runs ? tok->cap_runs * 2 : 64;
 		while (cap < tok->n_runs + runs)
 			cap *= 2;
 		struct akoKagariRun* p = realloc(tok->runs, cap * sizeof(struct akoKagariRun));

@@ -36,6 +36,10 @@ int akoHipDeviceCount(void);
 /* Reason of the last failure on this thread ("" if none). */
 const char* akoHipLastError(void);
 
+/* The AKO_HIP_* tuning / test knobs of the environment (kernel path, tail engine, segment length ...) are read when a
+ * plan is CREATED.  This folds their current values into one word, so that a cache of plans can tell when they moved. */
+uint64_t akoHipTuningSignature(void);
+
 /*
  * A plan fixes: device, settings, channel count, image size and batch size.  It owns the per level
  * geometry / quantizer tables (library/lifting.c:182-211 via library/quantization.c:67-98 -- computed
@@ -148,6 +152,62 @@ struct akoHipKagariRun
 int akoHipKagariExpand(akoHipPlan*, const int16_t* h_literals, size_t n_literals, const struct akoHipKagariRun* h_runs,
                        size_t n_runs, void* d_streams, size_t image);
 int akoHipDecodeDownload(akoHipPlan*, void* h_images);
+
+/* ---- ratio search support: transform once, quantize per candidate ---------------------------
+ * The quantization factor only enters the forward path where the C / B / D sub-bands are stored
+ * (library/lifting.c:154-168) and in the lift heads (library/lifting.c:253-267).  A search over quantizations
+ * (tools/akoenc.cpp:130-214) therefore transforms ONCE on a plan created with quantization 0 and gate 0 (and the colour
+ * the candidates will have: see akoHipEffectiveColor), and per candidate calls
+ *
+ * akoHipRequantize      streams of that plan (d_unquantized, NULL = the plan's own buffer as left by akoHipEncodeUpload)
+ *                       -> plan-owned streams (*d_out) that are bit-identical to encoding the pixels with
+ *                       (quantization, gate); feed them to akoHipKagariEncode.  Synchronous.
+ * akoHipPlanDeviceImages / akoHipPlanDeviceStreams   the plan's own staging buffers (device addresses)
+ * akoEncodeRatioExt     the whole search of tools/akoenc.cpp:112-217 behind one call: same bracketing and bisection,
+ *                       same chosen quantization and same blob as repeated akoEncodeExt calls, with one upload and
+ *                       one transform per distinct colour transformation (at most two).  *out_quantization: the
+ *                       factor it settled on; *out_encodes: how many candidate encodes it replaced */
+int akoHipRequantize(akoHipPlan*, int quantization, int gate, const void* d_unquantized, void** d_out);
+void* akoHipPlanDeviceImages(akoHipPlan*);
+void* akoHipPlanDeviceStreams(akoHipPlan*);
+size_t akoEncodeRatioExt(const struct akoCallbacks*, const struct akoSettings*, size_t channels, size_t image_w,
+                         size_t image_h, const void* in, int ratio, void** out, int* out_quantization, int* out_encodes,
+                         int* out_transforms, enum akoStatus* out_status);
+
+/* akoEncodeExt / akoDecodeExt keep the device plan of a thread's previous call (same shape and settings: the next
+ * call reuses it).  When a thread exits its plans are parked in a small process-wide pool, where the next thread
+ * that needs the same shape finds them (what does not fit is destroyed by the next thread that enters the library).
+ * akoHipThreadRelease() destroys the calling thread's plans and everything parked, at once. */
+void akoHipThreadRelease(void);
+
+/* ---- batched host API ---------------------------------------------------------------
+ * Many equally shaped images from host memory to .ako blobs (and back) at link rate: the per-image loop of
+ * tools/akoenc.cpp:112-217 / tools/akodec.cpp:100-154 over a whole array, BASELINE configs[3].  A batch object owns,
+ * per device, a few LANES: a plan with its own HIP stream plus pinned staging buffers.  A call deals the images to
+ * the lanes of all devices (worker threads of the library; the caller just waits), so that on every device the
+ * upload of one image, the transform + entropy stage of another and the download of a third overlap.  Blobs are
+ * byte-identical to akoEncodeExt's for the same image and settings.
+ *
+ * akoHipBatchCreate   devices: n_devices HIP device indices (NULL: device 0; a device may appear more than once);
+ *                     lanes_per_device 0 = default (3)
+ * akoHipEncodeBatch   images[i]: image_w * image_h * channels bytes each.  out_blobs[i] / out_sizes[i]: a malloc'ed
+ *                     blob per image (release with akoDefaultFree), NULL / 0 where out_status[i] != AKO_OK
+ *                     (out_status may be NULL).  Returns 0 when every image was encoded
+ * akoHipDecodeBatch   blobs of images of the batch's shape -> images[i] (caller's buffers of image bytes each) */
+typedef struct akoHipBatch akoHipBatch;
+akoHipBatch* akoHipBatchCreate(const int* devices, size_t n_devices, size_t lanes_per_device,
+                               const struct akoSettings* settings, size_t channels, size_t image_w, size_t image_h,
+                               enum akoStatus* out_status);
+void akoHipBatchDestroy(akoHipBatch*);
+size_t akoHipBatchLanes(const akoHipBatch*);
+int akoHipEncodeBatch(akoHipBatch*, size_t n_images, const void* const* images, void** out_blobs, size_t* out_sizes,
+                      enum akoStatus* out_status);
+int akoHipDecodeBatch(akoHipBatch*, size_t n_blobs, const void* const* blobs, const size_t* blob_sizes, void** images,
+                      enum akoStatus* out_status);
+
+/* pinned host memory (hipHostMalloc): page-locked, so copies to / from the device run at link rate and asynchronously */
+void* akoHipHostAlloc(size_t bytes);
+void akoHipHostFree(void* p);
 
 #ifdef __cplusplus
 }

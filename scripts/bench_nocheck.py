@@ -21,4 +21,4 @@ with api.Plan(s, 4, w, h) as plan:
     for r in plan.kernel_records(False) + plan.kernel_records(True):
         agg[(r["name"], r["level"])].append(r["ms"])
     tot = sum(sum(v) / len(v) for v in agg.values())
-    print("sum_kernel_ms %.4f" % tot, [(k[0], k[1], round(sum(v) / len(v), 4)) for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:4]])
+    print("sum_kernel_ms %.4f" % tot, [(k[0], k[1], round(sum(v) / len(v), 4)) for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:int(os.environ.get("TOP", "16"))]])

@@ -373,3 +373,26 @@ def test_synthetic_generators_match_the_oracle_and_the_survey_anchors(po, golden
     assert f"{po.adler32(api.synth_image(0, 64, 64)):08x}" == "15173ae6"
     assert f"{po.adler32(api.synth_image(0, 100, 75)):08x}" == "189d0ecc"
     assert f"{po.adler32(api.synth_image(1, 100, 75)):08x}" == "57cbae7c"
+
+
+def test_forged_heads_are_rejected_before_anything_is_sized_from_them(po):
+    """A 16 byte head is all an attacker needs to write: 2^32-1 x 2^32-1 pixels in 8 pixel tiles asks for
+    ~10^17 tile records; w = h = 2^31 with 4 channels wraps w*h*channels to 0.  akoDecodeExt must answer with a
+    status -- not abort, not allocate -- and must do so before it looks for a device (so this runs without one)."""
+    def head(w, h, ch, tiles_log2_minus2, compression):
+        flags = (ch - 1) | (0 << 4) | (0 << 6) | (0 << 8) | (compression << 10) | (tiles_log2_minus2 << 12)
+        return np.frombuffer(bytes([65, 107, 111, 2]) + int(w).to_bytes(4, "little") + int(h).to_bytes(4, "little") +
+                             int(flags).to_bytes(4, "little"), dtype=np.uint8)
+
+    big = 0xFFFFFFFF
+    for blob, allowed in [
+        (head(big, big, 4, 1, 0), (13, 15)),              # Kagari, 8 px tiles: 2.9e17 tiles in a 16 byte blob
+        (head(big, big, 16, 0, 2), (13, 15)),             # no compression, untiled: 2^68 bytes of stream
+        (head(1 << 31, 1 << 31, 4, 0, 0), (13, 15)),      # w*h*ch*2 = 2^65 wraps
+        (head(1 << 20, 1 << 20, 4, 1, 0), (13, 15)),      # 1.7e10 tiles, blob of 16 bytes
+        (np.concatenate([head(4096, 4096, 4, 1, 0), np.zeros(1000, np.uint8)]), (15,)),  # 262144 tiles need >= 1.3 MB
+        (np.concatenate([head(64, 64, 4, 0, 2), np.zeros(100, np.uint8)]), (15,)),       # raw stream shorter than w*h*ch*2
+    ]:
+        with pytest.raises(api.AkoError) as e:
+            api.decode(blob)
+        assert e.value.status in allowed, (blob[:16].tobytes().hex(), e.value.status)  # 13 no memory, 15 broken input

@@ -1,0 +1,97 @@
+"""GPU: the batched host API (include/ako_hip.h akoHipBatch*) and the multi-device routes.
+
+Every blob a batch call returns must be byte-identical to what akoEncodeExt returns for the same image, which in turn is
+the oracle's blob; decoded images likewise.  The 1-GPU test box runs the multi-device logic with a device list that
+names device 0 more than once (bands / lanes are then separate plans and streams on the same GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from ako_amd import api  # noqa: E402
+
+
+def test_encode_batch_equals_per_image_encode_and_the_oracle(po):
+    w, h, n = 640, 360, 24
+    imgs = [po.gen_image(0, w, h, seed=0x9E3779B9 + i) for i in range(n)]   # configs[3] seeding rule
+    for (comp, q, g, td) in [(api.KAGARI, 16, 16, 0), (api.COMPRESSION_NONE, 16, 16, 0), (api.KAGARI, 0, 0, 128)]:
+        s = api.settings(wavelet=api.DD137 if q else api.CDF53, compression=comp, q=q, g=g, tiles=td)
+        with api.Batch(s, 4, w, h, devices=[0, 0], lanes_per_device=2) as b:
+            assert b.lanes == 4
+            blobs, st = b.encode(imgs)
+            assert st == [0] * n
+            for i in (0, 7, n - 1):
+                want, ost = po.encode_image(po.settings(wavelet=s.wavelet, compression=comp, q=q, g=g, tiles=td), imgs[i])
+                assert ost == 0 and np.array_equal(blobs[i], want), (comp, q, td, i)
+            for i in range(n):
+                assert np.array_equal(blobs[i], api.encode(imgs[i], s)), (comp, q, td, i)
+            # and back
+            decs, st = b.decode(blobs)
+            assert st == [0] * n
+            for i in range(n):
+                want, _, _ = po.decode_image(blobs[i])
+                assert np.array_equal(decs[i], want), (comp, q, td, i)
+
+
+def test_batch_reports_per_image_failures(po):
+    import ctypes as C
+
+    w, h = 256, 128
+    s = api.settings(wavelet=api.CDF53, compression=api.KAGARI, q=0, g=0)
+    good = po.gen_image(0, w, h)
+    want, ost = po.encode_image(po.settings(wavelet=1, compression=0, q=0, g=0), good)
+    assert ost == 0
+    with api.Batch(s, 4, w, h) as b:
+        # encode: a missing image fails alone, its neighbours come through
+        ptrs = (C.c_void_p * 3)(good.ctypes.data, None, good.ctypes.data)
+        out, sizes, st = (C.c_void_p * 3)(), (C.c_size_t * 3)(), (C.c_int * 3)()
+        rc = api.lib().akoHipEncodeBatch(b._b, 3, ptrs, out, sizes, st)
+        assert rc != 0 and list(st) == [0, 9, 0] and not out[1] and sizes[1] == 0     # 9 = AKO_INVALID_INPUT
+        for i in (0, 2):
+            got = np.ctypeslib.as_array(C.cast(out[i], C.POINTER(C.c_uint8)), shape=(sizes[i],)).copy()
+            api.lib().akoDefaultFree(out[i])
+            assert np.array_equal(got, want)
+        # decode: a truncated blob and a blob of another shape fail alone
+        other = api.encode(po.gen_image(0, 64, 64), s)
+        decs, st = b.decode([want, want[:200], other, want])
+        assert st[0] == 0 and st[1] == 15 and st[2] != 0 and st[3] == 0
+        assert np.array_equal(decs[0], good) and np.array_equal(decs[3], good) and decs[1] is None
+
+
+def test_tiled_image_over_several_devices_matches_the_single_device_blob(po, golden_sums):
+    """akoEncodeExt / akoDecodeExt of a TILED image split over the devices named by AKO_HIP_DEVICES
+    (bands of whole tile rows, library/encode.c:115-205; the host joins the bodies in tile order).  Device 0 is named
+    once per band here, so the band logic runs on a one-GPU box too; with more GPUs visible the second band goes to
+    device 1."""
+    ndev = api.device_count()
+    second = 1 if ndev > 1 else 0
+    old = os.environ.get("AKO_HIP_DEVICES")
+    try:
+        for (w, h, ch, td, wavelet, q, comp) in [(1000, 777, 4, 256, 0, 16, 2), (1000, 777, 4, 256, 0, 16, 0), (300, 200, 3, 64, 1, 0, 0),
+                                                 (517, 1031, 4, 128, 0, 16, 0), (96, 64, 4, 64, 2, 0, 2)]:
+            img = np.ascontiguousarray(po.gen_image(1 if comp == 2 else 0, w, h)[:, :, :ch])
+            want, ost = po.encode_image(po.settings(wavelet=wavelet, compression=comp, q=q, g=q, tiles=td), img)
+            assert ost == 0
+            dec_want, _, _ = po.decode_image(want)
+            for devs in (f"0,{second}", f"0,{second},0", "0"):
+                os.environ["AKO_HIP_DEVICES"] = devs
+                s = api.settings(wavelet=wavelet, compression=comp, q=q, g=q, tiles=td)
+                events = []
+                blob = api.encode(img, s, events=lambda t, n, e: events.append((t, n, e)))
+                assert np.array_equal(blob, want), (w, h, td, devs)
+                tiles = ((w + td - 1) // td) * ((h + td - 1) // td)
+                assert [e[0] for e in events if e[2] == 1] == list(range(tiles))   # FORMAT_START of every tile, in order
+                dec, _ = api.decode(blob)
+                assert np.array_equal(dec, dec_want), (w, h, td, devs)
+        # the anchor of SURVEY 8c: G1 1000x777 DD137 q16 g16 tiles 256, blob adler 370428a2
+        os.environ["AKO_HIP_DEVICES"] = f"0,{second}"
+        blob = api.encode(po.gen_image(1, 1000, 777), api.settings(wavelet=0, compression=2, q=16, g=16, tiles=256))
+        assert blob.size == 6231936 and f"{po.adler32(blob):08x}" == "370428a2"
+    finally:
+        if old is None:
+            os.environ.pop("AKO_HIP_DEVICES", None)
+        else:
+            os.environ["AKO_HIP_DEVICES"] = old

@@ -1,6 +1,6 @@
-"""Device entropy stage: the GPU Kagari encoder must produce, bit for bit, what the host
-restatement of library/kagari.c produces (ako_amd/csrc/host/ako_kagari.c, itself pinned against the oracle
-and the compiled reference in tests/test_cabi_host.py and tests/test_oracle_vs_ref.py)."""
+"""Device entropy stage: the GPU Kagari encoder must produce, bit for bit, what the ORACLE's
+restatement of library/kagari.c produces (oracle/ako_oracle.c: orcKagariEncode, pinned against the compiled
+reference in tests/test_oracle_vs_ref.py) -- and so must the product's own host coder, checked alongside."""
 import ctypes as C
 import struct
 import zlib
@@ -12,8 +12,12 @@ from ako_amd import api
 
 
 def host_body(plan, streams_i16: np.ndarray):
-    """[uint32 size][payload] per tile with the HOST encoder, or the index of the first tile that fails."""
-    L = api.lib()
+    """[uint32 size][payload] per tile with the ORACLE's encoder (the checker), or the index of the first tile that
+    fails; the product's host coder (akoHostKagariEncode, same .so as the device coder) must agree with it."""
+    from oracle import pyoracle as po
+
+    po.build()
+    L, O = api.lib(), po.lib()
     out = bytearray()
     raw = streams_i16.view(np.uint8)
     for t in range(plan.tiles):
@@ -21,7 +25,10 @@ def host_body(plan, streams_i16: np.ndarray):
         off, n = ti["stream_offset"], ti["stream_bytes"]
         src = np.ascontiguousarray(raw[off:off + n])
         dst = np.zeros(n + 16, dtype=np.uint8)
-        size = L.akoHostKagariEncode(n, n - 4, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+        size = O.orcKagariEncode(n, n - 4, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+        mine = np.zeros(n + 16, dtype=np.uint8)
+        size2 = L.akoHostKagariEncode(n, n - 4, src.ctypes.data_as(C.c_void_p), mine.ctypes.data_as(C.c_void_p))
+        assert size2 == size and np.array_equal(mine[:size], dst[:size]), f"host coder differs from the oracle on tile {t}"
         if size == 0:
             return None, t
         out += struct.pack("<I", size) + dst[:size].tobytes()

@@ -207,7 +207,8 @@ def test_level_widths_not_multiples_of_4(po, path_mode):
     engine), 4 / 3 / 2 / 1 channels, adversarial streams, lifting-only planes; in 'auto' mode level 0 of a
     wide case must actually have streamed."""
     nrng = np.random.default_rng(55)
-    cases = [(250, 40, 4, 0), (502, 34, 4, 0), (1366, 36, 4, 0), (742, 130, 3, 0), (990, 30, 1, 0),
+    # (w, h, channels, tiles): the tiled ones put the odd widths into the edge tiles (1366 = 2 * 512 + 342, ...)
+    cases = [(250, 40, 4, 0), (502, 34, 4, 0), (1366, 36, 4, 512), (742, 130, 3, 0), (990, 30, 1, 256),
              (1366, 70, 4, 0), (246, 64, 4, 0), (242, 40, 4, 0), (486, 33, 4, 0), (482, 33, 3, 0),
              # odd widths: phantom last sample, with an even (251, 1367, 487) and an odd (253, 1001, 245) column count
              (251, 40, 4, 0), (253, 41, 4, 0), (1001, 35, 4, 0), (1367, 37, 4, 0), (487, 64, 3, 0), (245, 33, 1, 0),
@@ -217,9 +218,7 @@ def test_level_widths_not_multiples_of_4(po, path_mode):
             for wrap in range(4):
                 q = int(nrng.choice([0, 16]))
                 img = nrng.integers(0, 256, (h, w, ch), dtype=np.uint8)
-                s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=q // 2, tiles=0)
-                if td:
-                    continue  # (tiles must be powers of two: the tiled case is covered by the odd image sizes above)
+                s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=q // 2, tiles=td)
                 ob, st = po.encode_image(s, img)
                 assert st == 0
                 body = hip_encode_body(img, s)
@@ -742,18 +741,55 @@ def test_api_plan_cache_and_threads(po):
             os.environ["AKO_HIP_PLAN_CACHE"] = old
 
 
-def test_profiling_records(po):
-    img = po.gen_image(0, 512, 512)
-    with api.Plan(api.settings(wavelet=0, compression=2, q=16, g=16), 4, 512, 512) as plan:
-        plan.set_profiling(True)
-        d_img = torch.from_numpy(img).cuda().reshape(1, 512, 512, 4)
-        st = plan.encode(d_img)
-        plan.decode(st)
-        plan.synchronize()
-        enc, dec = plan.kernel_records(False), plan.kernel_records(True)
-        assert plan.levels() == 8
-        assert 2 <= len(enc) <= 8 and len(enc) <= len(dec) <= len(enc) + 1   # fused tail; optimistic + exact pair
-        assert enc[0]["name"] in ("fwd_level_dd137_u8", "fwd_stream_dd137_u8")
-        assert dec[-1]["name"].startswith(("inv_level_dd137_u8", "inv_stream_dd137_u8"))
-        assert all(r["ms"] > 0 for r in enc + dec)
-        assert enc[0]["bytes_rd"] == 512 * 512 * 4
+def test_api_cached_plans_die_with_their_thread(po):
+    """The per-thread plan cache of akoEncodeExt / akoDecodeExt hangs off a pthread key (ako_codec.c).  A thread that
+    exits parks its plans in a small process-wide pool (it cannot free device memory itself any more); later threads
+    of the same shape reuse them, the overflow is destroyed by the next live caller, and akoHipThreadRelease() empties
+    everything.  32 short-lived threads, each encoding and decoding a 1024x1024 RGBA image (a plan pair of roughly
+    70 MB of device memory): what stays allocated must be bounded by the pool, not grow with the thread count -- it
+    used to grow by one plan pair per exited thread -- and must all come back on release."""
+    import threading
+
+    import torch
+
+    api.lib().akoHipThreadRelease()
+    torch.cuda.synchronize()
+    free_start, _ = torch.cuda.mem_get_info()
+    img = po.gen_image(0, 1024, 1024)
+    s = api.settings(wavelet=0, compression=0, q=16, g=16)
+    blob = api.encode(img, s)
+    want, _ = api.decode(blob)
+    errors = []
+
+    def work():
+        try:
+            b = api.encode(img, s)
+            d, _ = api.decode(b)
+            if not (np.array_equal(b, blob) and np.array_equal(d, want)):
+                errors.append("output differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def rounds(n):
+        for _ in range(n):
+            threads = [threading.Thread(target=work) for _ in range(8)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    free_a = rounds(2)    # 16 threads have come and gone
+    work()                # a live caller: reaps what did not fit into the pool
+    free_a = torch.cuda.mem_get_info()[0]
+    free_b = rounds(4)    # 32 more
+    work()
+    free_b = torch.cuda.mem_get_info()[0]
+    assert not errors, errors[:3]
+    # bounded: twice as many exited threads do not hold more memory (one leaked pair per thread would be ~2 GB more)
+    assert free_a - free_b < 128 << 20, f"device memory keeps shrinking with exited threads: {(free_a - free_b) >> 20} MiB"
+    api.lib().akoHipThreadRelease()
+    torch.cuda.synchronize()
+    free_end, _ = torch.cuda.mem_get_info()
+    assert free_start - free_end < 64 << 20, f"not everything came back on release: {(free_start - free_end) >> 20} MiB"
