@@ -186,6 +186,11 @@ def lib() -> C.CDLL:
     L.akoHipEncodeBatch.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int)]
     L.akoHipDecodeBatch.restype = C.c_int
     L.akoHipDecodeBatch.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(C.c_int)]
+    L.akoEncodeRatioExt.restype = sz
+    L.akoEncodeRatioExt.argtypes = [C.POINTER(Callbacks), C.POINTER(Settings), sz, sz, sz, vp, C.c_int, C.POINTER(vp),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.akoHipRequantize.restype = C.c_int
+    L.akoHipRequantize.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.akoHipHostAlloc.restype = vp
     L.akoHipHostAlloc.argtypes = [sz]
     L.akoHipHostFree.restype = None
@@ -269,6 +274,23 @@ def encode(image: np.ndarray, s: Optional[Settings] = None, events=None) -> np.n
     blob = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n,)).copy()
     lib().akoDefaultFree(out)
     return blob
+
+
+def encode_ratio(image: np.ndarray, ratio: int, s: Optional[Settings] = None):
+    """akoEncodeRatioExt: the quantization search of tools/akoenc.cpp:112-217 in one call ->
+    (blob, quantization it settled on, candidate encodes it replaced, forward transforms it ran)."""
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = image.shape[:2]
+    ch = 1 if image.ndim == 2 else image.shape[2]
+    out = C.c_void_p()
+    st, q, enc, tr = C.c_int(-1), C.c_int(0), C.c_int(0), C.c_int(0)
+    n = lib().akoEncodeRatioExt(None, C.byref(s) if s is not None else None, ch, w, h, image.ctypes.data_as(C.c_void_p),
+                                ratio, C.byref(out), C.byref(q), C.byref(enc), C.byref(tr), C.byref(st))
+    if n == 0:
+        raise AkoError(st.value, "akoEncodeRatioExt", last_error())
+    blob = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    lib().akoDefaultFree(out)
+    return blob, q.value, enc.value, tr.value
 
 
 def decode(blob, events=None):

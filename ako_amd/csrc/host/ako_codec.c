@@ -1228,7 +1228,7 @@ AKO_API size_t akoEncodeRatioExt(const struct akoCallbacks* c, const struct akoS
 		u.color = color_q;
 		if ((rs.plan_q = akoHipPlanCreate(chosen_device(), &u, channels, image_w, image_h, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &status)) == NULL)
 			goto failure;
-		if (color_0 != color_q)
+		if (color_0 != color_q && channels >= 3) /* below three channels no colour transformation runs (format.c:87) */
 		{
 			u.color = color_0;
 			if ((rs.plan_0 = akoHipPlanCreate(chosen_device(), &u, channels, image_w, image_h, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &status)) == NULL)

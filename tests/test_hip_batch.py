@@ -95,3 +95,81 @@ def test_tiled_image_over_several_devices_matches_the_single_device_blob(po, gol
             os.environ.pop("AKO_HIP_DEVICES", None)
         else:
             os.environ["AKO_HIP_DEVICES"] = old
+
+
+def _search_by_reencoding(img, ratio, base):
+    """tools/akoenc.cpp:130-214 step for step, every candidate a full akoEncodeExt (what the tools did before N4)."""
+    def run(q):
+        s = base.copy()
+        s.quantization = q
+        try:
+            return api.encode(img, s)
+        except api.AkoError:
+            return None
+    size = lambda b: 0 if b is None else b.size
+    target = img.size // ratio
+    margin = target * 4 // 100
+    runs = 1
+    last = run(0)
+    ceil_size = floor_size = size(last)
+    ceil_q = floor_q = 0
+    q = 1
+    while True:
+        q *= 4
+        ceil_size, ceil_q = floor_size, floor_q
+        last = run(q)
+        runs += 1
+        floor_size, floor_q = size(last), q
+        if not floor_size > target:
+            break
+    last_size = floor_size
+    while abs(floor_size - ceil_size) > margin and abs(floor_q - ceil_q) > 1:
+        q = (ceil_q + floor_q) // 2
+        last = run(q)
+        runs += 1
+        last_size = size(last)
+        if last_size > target:
+            ceil_size, ceil_q = last_size, q
+        else:
+            floor_size, floor_q = last_size, q
+    take_floor = abs(floor_size - target) < abs(ceil_size - target)
+    best_q, best_size = (floor_q, floor_size) if take_floor else (ceil_q, ceil_size)
+    if last_size != best_size:
+        last = run(best_q)
+        runs += 1
+    return last, runs
+
+
+def test_ratio_search_on_one_transform_gives_the_blob_of_repeated_encodes(po, golden_sums):
+    """akoEncodeRatioExt transforms once per colour transformation and re-quantizes per candidate; the
+    blob (and therefore the quantization it settles on) must be the one the search by repeated akoEncodeExt calls
+    ends with, and the golden `ratio20` file of the reference's own akoenc."""
+    import zlib
+
+    img512 = po.gen_image(0, 512, 512)
+    blob, q, encodes, transforms = api.encode_ratio(img512, 20, api.default_settings())
+    assert blob.size == 51597 and f"{zlib.adler32(blob.tobytes()) & 0xFFFFFFFF:08x}" == "a6c44283"   # tests/golden/cli.json ratio20
+    assert transforms == 2 and encodes >= 4     # quantization 0 keeps plain YCoCg, every other candidate YCoCg_Q
+    cases = [(img512, 20, api.default_settings()),
+             (img512, 8, api.settings(wavelet=api.CDF53)),
+             (img512, 12, api.settings(g=8)),                                    # gate > 0: one colour, ONE transform
+             (img512, 30, api.settings(color=api.SUBTRACT_G, tiles=128)),        # tiled, colour independent of q
+             (np.ascontiguousarray(po.gen_image(0, 300, 200)[:, :, :3]), 10, api.settings(wrap=api.MIRROR, chroma_loss=2)),
+             (np.ascontiguousarray(po.gen_image(0, 97, 131)[:, :, :1]), 6, api.settings(wavelet=api.HAAR))]
+    for (img, ratio, base) in cases:
+        blob, q, encodes, transforms = api.encode_ratio(img, ratio, base)
+        want, runs = _search_by_reencoding(img, ratio, base)
+        assert want is not None and np.array_equal(blob, want), (img.shape, ratio)
+        assert encodes == runs
+        one_colour = base.color != api.YCOCG or base.gate > 0 or img.shape[2] < 3
+        assert transforms == (1 if one_colour else 2), (img.shape, ratio, transforms)
+        # and it is the oracle's blob for that quantization
+        s = po.settings(wavelet=base.wavelet, color=base.color, wrap=base.wrap, compression=0, tiles=base.tiles_dimension,
+                        q=q, g=base.gate, chroma_loss=base.chroma_loss)
+        ob, ost = po.encode_image(s, img)
+        assert ost == 0 and np.array_equal(blob, ob), (img.shape, ratio, q)
+    # no search for ratio 0 / 1 (tools/akoenc.cpp:116-128)
+    b0, q0, e0, _ = api.encode_ratio(img512, 0, api.default_settings())
+    assert np.array_equal(b0, api.encode(img512, api.default_settings())) and e0 == 1 and q0 == 16
+    b1, q1, _, _ = api.encode_ratio(img512, 1, api.default_settings())
+    assert np.array_equal(b1, api.encode(img512, api.settings(q=0, g=0))) and q1 == 0

@@ -5,10 +5,14 @@
 // (tools/benchmark.hpp:60-84), '-ch' Adler-32 of the input pixels, and the '-dev-r' ratio search
 // (:111-214).  Opt-in extras that the reference does not have: '--tiles', '--device'.
 #include "ako.h"
+#include "ako_hip.h"  // akoEncodeRatioExt: the ratio search as one call
 #include "cli_common.hpp"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 
 namespace
 {
@@ -56,7 +60,7 @@ void on_event(size_t tile_no, size_t total_tiles, enum akoEvent e, void* user)
 // The search follows the reference step for step (tools/akoenc.cpp:111-214) so that the same input
 // ends in the same quantization and therefore in the same file.
 size_t encode_pass(bool verbose, int ratio, const akoCallbacks& cb, const akoSettings& base, const cli::Image& img,
-                   void** blob, akoStatus* status)
+                   void** blob, akoStatus* status, std::string* search_note = nullptr)
 {
 	auto run = [&](const akoSettings& s) {
 		return akoEncodeExt(&cb, &s, img.channels, img.width, img.height, img.pixels.data(), blob, status);
@@ -69,6 +73,27 @@ size_t encode_pass(bool verbose, int ratio, const akoCallbacks& cb, const akoSet
 	{
 		s.quantization = 0, s.gate = 0;
 		return run(s);
+	}
+
+	// The search as ONE library call (include/ako_hip.h: akoEncodeRatioExt): same bracketing and bisection, same
+	// winner, same file -- with the pixels uploaded once and the image transformed once per colour transformation,
+	// each candidate costing a re-quantization pass and the device entropy stage.  '-verbose' keeps the loop below,
+	// which prints every step as the reference tool does.
+	if (!verbose && std::getenv("AKOENC_SEARCH_BY_REENCODING") == nullptr)
+	{
+		int q = 0, encodes = 0, transforms = 0;
+		cli::Timer t;
+		t.start(true);
+		const size_t size = akoEncodeRatioExt(&cb, &base, img.channels, img.width, img.height, img.pixels.data(), ratio, blob,
+		                                      &q, &encodes, &transforms, status);
+		if (search_note != nullptr && size != 0)
+		{
+			char line[160];
+			std::snprintf(line, sizeof line, "Ratio search: quantization %i after %i candidates on %i transform%s, %g ms", q,
+			              encodes, transforms, transforms == 1 ? "" : "s", t.stop());
+			*search_note = line;
+		}
+		return size;
 	}
 
 	const size_t target = (img.width * img.height * img.channels) / (size_t)ratio;
@@ -221,11 +246,14 @@ int main(int argc, const char* argv[])
 				std::printf("Benchmark: \n");
 			}
 		}
-		const size_t blob_size = encode_pass(verbose, ratio, cb, s, img, &blob, &status);
+		std::string search_note;
+		const size_t blob_size = encode_pass(verbose, ratio, cb, s, img, &blob, &status, &search_note);
 		if (timing)
 		{
 			if (ratio != 0)
 				std::printf("Benchmark: \n");
+			if (!search_note.empty())
+				std::printf(" - %s\n", search_note.c_str());
 			std::printf(" - Total: %g ms\n", total.stop());
 		}
 		if (blob_size == 0)
