@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Callable, Optional
 
 import numpy as np
@@ -173,6 +174,9 @@ def lib() -> C.CDLL:
     L.akoHostKagariEncode.argtypes = [sz, sz, vp, vp]
     L.akoHostKagariDecode.restype = sz
     L.akoHostKagariDecode.argtypes = [sz, sz, sz, vp, vp]
+    if not hasattr(L, "akoHipBatchCreate"):  # an older build of the library (timing comparisons): the common subset only
+        _lib = L
+        return L
     L.akoHipThreadRelease.restype = None
     L.akoHipThreadRelease.argtypes = []
     L.akoHipTuningSignature.restype = C.c_uint64
@@ -306,9 +310,16 @@ def decode(blob, events=None):
     del keep
     if not p:
         raise AkoError(st.value, "akoDecodeExt", last_error())
-    img = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, ch.value)).copy()
-    lib().akoDefaultFree(p)
+    # the library's buffer IS the result (no copy: for a large image that copy costs more than the decode); it is
+    # released through akoDefaultFree when the array -- and every view of it -- is gone
+    n = h.value * w.value * ch.value
+    img = np.frombuffer((C.c_uint8 * n).from_address(p), dtype=np.uint8).reshape(h.value, w.value, ch.value).view(_Owned)
+    img._release = weakref.finalize(img, lib().akoDefaultFree, C.c_void_p(p))
     return img, s
+
+
+class _Owned(np.ndarray):
+    """An ndarray over memory the library allocated; freed when the array is collected."""
 
 
 # ---------------------------------------------------------------------------------------------

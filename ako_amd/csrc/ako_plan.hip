@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -128,6 +129,7 @@ struct Tuning
 	bool opt = true;       // AKO_HIP_OPT=0: exact int16-wrapping inverse alone (no optimistic fp32 launch)
 	bool staged = true;    // AKO_HIP_STAGED=0: no planar staging of 1-3 / 5+ channel u8 images
 	bool deep = true;      // AKO_HIP_DEEP=0: small levels keep the running two-slot prefetch
+	int u8_waves = 0;      // AKO_HIP_U8_WAVES: waves a u8 level launch aims at (0 = two rounds of resident waves)
 	uint32_t dbg = 0;      // AKO_HIP_DBG bits (kernel side experiments)
 
 	static Tuning from_env()
@@ -148,6 +150,7 @@ struct Tuning
 		t.opt = num("AKO_HIP_OPT", 1) != 0;
 		t.staged = num("AKO_HIP_STAGED", 1) != 0;
 		t.deep = num("AKO_HIP_DEEP", 1) != 0;
+		t.u8_waves = num("AKO_HIP_U8_WAVES", 0);
 		t.dbg = (uint32_t)num("AKO_HIP_DBG", 0);
 		return t;
 	}
@@ -187,6 +190,9 @@ struct akoHipPlan
 	int16_t* d_requant = nullptr;
 	void* d_rq_segments = nullptr;
 	size_t rq_segment_capacity = 0;
+	// chunked download of large images (download_chunked): two pinned staging buffers and their events
+	void* pin[2] = {nullptr, nullptr};
+	hipEvent_t pin_done[2] = {nullptr, nullptr};
 };
 
 namespace
@@ -253,7 +259,13 @@ struct Launch
 {
 	akoHipPlan* plan;
 	int decode;
+	hipStream_t on = nullptr;  // the stream the kernel is launched on (default: the plan's)
 	size_t ev = (size_t)-1;
+
+	hipStream_t stream() const
+	{
+		return on ? on : plan->stream;
+	}
 
 	int begin()
 	{
@@ -267,7 +279,7 @@ struct Launch
 			plan->events[decode].push_back(p);
 		}
 		ev = plan->events_used[decode]++;
-		HIP_TRY(hipEventRecord(plan->events[decode][ev].a, plan->stream));
+		HIP_TRY(hipEventRecord(plan->events[decode][ev].a, stream()));
 		return 0;
 	}
 	int end(const char* name, uint32_t level, uint32_t group, uint64_t units, uint64_t rd, uint64_t wr)
@@ -275,7 +287,7 @@ struct Launch
 		HIP_TRY(hipGetLastError());
 		if (!plan->profiling)
 			return 0;
-		HIP_TRY(hipEventRecord(plan->events[decode][ev].b, plan->stream));
+		HIP_TRY(hipEventRecord(plan->events[decode][ev].b, stream()));
 		akoHipPlan::Pending p;
 		memset(&p.rec, 0, sizeof p.rec);
 		snprintf(p.rec.name, sizeof p.rec.name, "%s", name);
@@ -387,6 +399,9 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 	for (const Group& g : pl->groups)
 		if (g.tile_values * 2 >= 0xFFF00000ull || (uint64_t)g.tile_w * g.tile_h * pl->channels * 2 >= 0xFFF00000ull)
 			return false;
+	// ... and their sources with a 32-bit row offset inside the image / plane (raw buffer loads)
+	if ((uint64_t)pl->w * pl->h * (u8 ? 4 : 2) >= 0xFFF00000ull)
+		return false;
 	if (mode == PATH_STREAM)
 		return true;
 	// a launch over many planes (tiled images, batches of tiles) fills the chip at any level size, and the
@@ -405,6 +420,7 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 	StreamGeom G;
 	G.strips = (L.tw + SNET - 1) / SNET;
 	G.wide = 0;
+	G.edge_rows = 0;
 	// 121..128 coefficient columns (an even number): one strip without halo lanes instead of two
 	if (L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && pl->tune.wide)
 		G.strips = 1, G.wide = 1;
@@ -413,12 +429,12 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		seg_rows = (uint32_t)pl->tune.seg_rows_big;
 	if (seg_rows == 0)
 	{
-		// aim at two rounds of resident waves: the u8 kernels run 3 waves per SIMD (6144 waves), the int16
+		// aim at two rounds of resident waves: the u8 kernels run 4 waves per SIMD (8192 waves), the int16
 		// ones 5 (10240).  Every segment re-computes 6 halo row slots, so big levels keep segments of >= 24
 		// rows; small levels are latency bound (a wave's row slots are a dependent chain) and prefer many
 		// short segments.  Rounded DOWN: a handful of waves over the target would cost a third round
 		const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
-		uint64_t segs = (u8 ? 6144 : 10240) / per_seg;
+		uint64_t segs = (u8 ? (uint64_t)(pl->tune.u8_waves > 0 ? pl->tune.u8_waves : 8192) : 10240) / per_seg;
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
@@ -430,6 +446,14 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		seg_rows = L.th;
 	G.seg_rows = seg_rows;
 	G.segs = (L.th + seg_rows - 1) / seg_rows;
+	G.edge_rows = 0;
+	// u8 kernels (128 VGPRs, the top / bottom border bodies spill): short segments at the two borders, see StreamGeom
+	constexpr uint32_t EDGE_ROWS = 12;
+	if (u8 && pl->tune.seg_rows == 0 && seg_rows > EDGE_ROWS && L.th >= 3 * EDGE_ROWS + seg_rows)
+	{
+		G.edge_rows = EDGE_ROWS;
+		G.segs = 3 + (L.th - 3 * EDGE_ROWS + seg_rows - 1) / seg_rows;
+	}
 	return G;
 }
 
@@ -470,6 +494,18 @@ void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, 
 		hipLaunchKernelGGL((k_inverse_stream<K_CDF53, NPL, U8, OPT, DEEP>), dim3(blocks), threads, 0, st, P, G);
 	else
 		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8, OPT, DEEP>), dim3(blocks), threads, 0, st, P, G);
+}
+
+template <bool OPT>
+void launch_inverse_u8(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, hipStream_t st)
+{
+	const dim3 pair(128);  // the workgroup is one pair of waves (LDS plane swap)
+	if (kind == K_DD137)
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_DD137, OPT>), dim3(blocks), pair, 0, st, P, G);
+	else if (kind == K_CDF53)
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_CDF53, OPT>), dim3(blocks), pair, 0, st, P, G);
+	else
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_HAAR, OPT>), dim3(blocks), pair, 0, st, P, G);
 }
 
 int check_blocks(uint64_t blocks)
@@ -762,8 +798,19 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				const int deep = deep_prefetch(pl, G, u8);
 				if (int rc = LA.begin())
 					return rc;
-				if (u8)
-					launch_forward_stream<2, true, 0>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
+				if (u8 && (pl->tune.dbg & 16))
+					hipLaunchKernelGGL(k_forward_stream_u8_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+				else if (u8)
+				{
+					if (L.kind == K_DD137)
+						hipLaunchKernelGGL((k_forward_stream_u8<K_DD137>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+					else if (L.kind == K_CDF53)
+						hipLaunchKernelGGL((k_forward_stream_u8<K_CDF53>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+					else
+						hipLaunchKernelGGL((k_forward_stream_u8<K_HAAR>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+				}
+				else if (pl->tune.dbg & 16)
+					hipLaunchKernelGGL(k_forward_stream_i16_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_forward_stream<1, false, DEEP_SLOTS_SHORT>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep)
@@ -887,7 +934,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 					Launch LO{pl, 1};
 					if (int rc = LO.begin())
 						return rc;
-					launch_inverse_stream<2, true, true, 0>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_u8<true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 					snprintf(name, sizeof name, "inv_stream_%s_u8", kind_name(L.kind));
 					const uint64_t smp = (uint64_t)L.cw * L.ch * pl->channels * insts;
 					const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
@@ -897,7 +944,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_inverse_stream<2, true, false, 0>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_u8<false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_inverse_stream<1, false, false, DEEP_SLOTS_SHORT>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep)
@@ -978,7 +1025,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;
@@ -1158,6 +1205,13 @@ void akoHipPlanDestroy(akoHipPlan* pl)
 		(void)hipFree(pl->d_flags);
 	if (pl->planes0)
 		(void)hipFree(pl->planes0);
+	for (int k = 0; k < 2; k++)
+	{
+		if (pl->pin[k])
+			(void)hipHostFree(pl->pin[k]);
+		if (pl->pin_done[k])
+			(void)hipEventDestroy(pl->pin_done[k]);
+	}
 	if (pl->d_requant)
 		(void)hipFree(pl->d_requant);
 	if (pl->d_rq_segments)
@@ -1282,6 +1336,79 @@ int akoHipSynchronize(akoHipPlan* pl)
 	return 0;
 }
 
+// Device -> pageable host memory for LARGE results.  One hipMemcpy into pageable memory is staged by the runtime
+// through its own pinned buffers and copied out by ONE host thread (about 19 GB/s for a 268 MB image); here the
+// device writes 16 MB chunks into two pinned buffers of the plan in turn (link rate), and while chunk k + 1 is on
+// the link a few host threads copy chunk k to its destination.
+constexpr size_t DL_CHUNK = (size_t)16 << 20;
+constexpr int DL_THREADS = 4;
+
+static int download_chunked(akoHipPlan* pl, void* h_dst, const void* d_src, size_t bytes)
+{
+	hipPointerAttribute_t attr;
+	const bool pinned = (hipPointerGetAttributes(&attr, h_dst) == hipSuccess && attr.type == hipMemoryTypeHost);
+	if (!pinned)
+		(void)hipGetLastError();  // plain malloc'ed memory: the query fails on purpose
+	if (pinned || bytes < 4 * DL_CHUNK)
+	{
+		HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, pl->stream));
+		HIP_TRY(hipStreamSynchronize(pl->stream));
+		return 0;
+	}
+	for (int k = 0; k < 2; k++)
+	{
+		if (!pl->pin[k] && hipHostMalloc(&pl->pin[k], DL_CHUNK, hipHostMallocDefault) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipHostMalloc(download staging) failed%s%s");
+		if (!pl->pin_done[k])
+			HIP_TRY(hipEventCreateWithFlags(&pl->pin_done[k], hipEventDisableTiming));
+	}
+	const size_t n = (bytes + DL_CHUNK - 1) / DL_CHUNK;
+	auto issue = [&](size_t k) -> int {
+		const size_t off = k * DL_CHUNK, len = (off + DL_CHUNK <= bytes) ? DL_CHUNK : bytes - off;
+		HIP_TRY(hipMemcpyAsync(pl->pin[k & 1], (const uint8_t*)d_src + off, len, hipMemcpyDeviceToHost, pl->stream));
+		HIP_TRY(hipEventRecord(pl->pin_done[k & 1], pl->stream));
+		return 0;
+	};
+	if (int rc = issue(0))
+		return rc;
+	if (n > 1)
+		if (int rc = issue(1))
+			return rc;
+	for (size_t k = 0; k < n; k++)
+	{
+		HIP_TRY(hipEventSynchronize(pl->pin_done[k & 1]));
+		const size_t off = k * DL_CHUNK, len = (off + DL_CHUNK <= bytes) ? DL_CHUNK : bytes - off;
+		uint8_t* dst = (uint8_t*)h_dst + off;
+		const uint8_t* src = (const uint8_t*)pl->pin[k & 1];
+		const size_t part = ((len / DL_THREADS) + 63) & ~(size_t)63;
+		std::thread helpers[DL_THREADS - 1];
+		int started = 0;
+		for (int t = 1; t < DL_THREADS; t++)
+		{
+			const size_t lo = (size_t)t * part;
+			if (lo >= len)
+				break;
+			const size_t cnt = (lo + part <= len) ? part : len - lo;
+			try
+			{
+				helpers[started] = std::thread([=] { memcpy(dst + lo, src + lo, cnt); });
+				started++;
+			}
+			catch (...)
+			{
+				memcpy(dst + lo, src + lo, cnt);  // no thread to be had: the caller copies this part too
+			}
+		}
+		memcpy(dst, src, part < len ? part : len);
+		for (int t = 0; t < started; t++)
+			helpers[t].join();
+		if (k + 2 < n)
+			if (int rc = issue(k + 2))
+				return rc;
+	}
+	return 0;
+}
+
 static int ensure_staging(akoHipPlan* pl)
 {
 	if (!pl->d_img)
@@ -1321,10 +1448,7 @@ int akoHipDecodeHost(akoHipPlan* pl, const void* h_streams, void* h_images)
 	                       pl->stream));
 	if (int rc = akoHipDecode(pl, pl->d_stream, pl->d_img))
 		return rc;
-	HIP_TRY(hipMemcpyAsync(h_images, pl->d_img, akoHipPlanImageBytes(pl) * pl->batch, hipMemcpyDeviceToHost,
-	                       pl->stream));
-	HIP_TRY(hipStreamSynchronize(pl->stream));
-	return 0;
+	return download_chunked(pl, h_images, pl->d_img, akoHipPlanImageBytes(pl) * pl->batch);
 }
 
 int akoHipPlanSetProfiling(akoHipPlan* pl, int enabled)
@@ -1708,10 +1832,7 @@ int akoHipDecodeDownload(akoHipPlan* pl, void* h_images)
 		return rc;
 	if (int rc = akoHipDecode(pl, pl->d_stream, pl->d_img))
 		return rc;
-	HIP_TRY(hipMemcpyAsync(h_images, pl->d_img, akoHipPlanImageBytes(pl) * pl->batch, hipMemcpyDeviceToHost,
-	                       pl->stream));
-	HIP_TRY(hipStreamSynchronize(pl->stream));
-	return 0;
+	return download_chunked(pl, h_images, pl->d_img, akoHipPlanImageBytes(pl) * pl->batch);
 }
 
 }  // extern "C"

@@ -51,6 +51,21 @@ __device__ __forceinline__ void static_for(F&& f)
 	static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
+// Cache policy (the aux operand of the raw buffer instructions; bit 1 = nt) of data that is touched ONCE: kept at
+// the default everywhere.  Measured on the box (scripts/ab_libs.sh / scripts/ab_steps.py, round 2): non-temporal
+// 4-byte-per-lane stream stores cost the level-0 forward kernel +15...35 % (although the level-1 kernel behind it
+// then finds its input still in the memory-side cache, -25 %), non-temporal pixel loads +10 % (the second wave
+// of a pair relies on finding the first one's lines in L2); on the inverse side non-temporal stream loads and
+// pixel stores take 4-5 % off the level-0 kernel run alone but cost 5 % of the throughput with four steps in
+// flight.  (-DAKO_INV_POLICY=2 rebuilds with the inverse hint for experiments.)
+#ifndef AKO_INV_POLICY
+#define AKO_INV_POLICY 0
+#endif
+constexpr int AUX_FWD_PIXEL_LOAD = 0;
+constexpr int AUX_FWD_STREAM_STORE = 0;
+constexpr int AUX_INV_STREAM_LOAD = AKO_INV_POLICY;
+constexpr int AUX_INV_PIXEL_STORE = AKO_INV_POLICY;
+
 constexpr int SNET = 120;  // net coefficient columns per wave
 constexpr int SORG = 4;    // lane 0 holds coefficient columns strip * SNET - SORG, +1
 constexpr int SWAVES = THREADS / 64;
@@ -419,7 +434,33 @@ struct StreamGeom
 {
 	uint32_t strips, segs, seg_rows;
 	uint32_t wide;  // one strip without halo lanes covers the whole tile width (121..128 coefficient columns)
+	// edge_rows != 0: the first segment and the last two are only edge_rows long, the segments between them seg_rows
+	// (the last of those possibly shorter).  The segments that touch the top / bottom border run the register-hungry
+	// border bodies (spilling in the 128-VGPR u8 kernels) and sit at the end of the grid: kept short, their waves
+	// finish with everybody else's instead of being the tail of the launch.
+	uint32_t edge_rows;
 };
+
+// rows [r_lo, r_hi) of a segment and its nominal length
+__host__ __device__ __forceinline__ void segment_rows(const StreamGeom& G, uint32_t seg, int Tr, int& r_lo, int& r_hi, int& len)
+{
+	if (G.edge_rows == 0)
+	{
+		r_lo = (int)seg * (int)G.seg_rows, len = (int)G.seg_rows;
+		r_hi = (r_lo + len < Tr) ? r_lo + len : Tr;
+		return;
+	}
+	const int E = (int)G.edge_rows, mid = (int)G.segs - 3;  // segments 1 .. mid are the long ones
+	if (seg == 0)
+		r_lo = 0, len = E, r_hi = E;
+	else if ((int)seg <= mid)
+	{
+		r_lo = E + ((int)seg - 1) * (int)G.seg_rows, len = (int)G.seg_rows;
+		r_hi = (r_lo + len < Tr - 2 * E) ? r_lo + len : Tr - 2 * E;
+	}
+	else
+		r_lo = Tr - ((int)G.segs - (int)seg) * E, len = E, r_hi = r_lo + E;
+}
 
 // unit -> (strip, segment, plane group, tile instance)
 struct UnitId
@@ -445,6 +486,7 @@ __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const Stream
 	uint64_t u = (uint64_t)blk * (blockDim.x >> 6) + wave;
 	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
 	id.valid = u < total;
+
 	id.pg = (uint32_t)(u % P.plane_groups);
 	// the two waves of a u8 pair do unequal work (forward: Y + Cg against Co + alpha) and wave w of a
 	// workgroup runs on SIMD w % 4: swap the roles in every other workgroup (by bit parity, which does not
@@ -510,10 +552,33 @@ struct LaneCols
 // are tile borders, where nothing real lies beyond: the WIDE strip starts at column 0 in lane 0, stores from
 // all its in-range lanes, and takes the taps across the borders from border_values() instead of from
 // out-of-range lanes (right side: only when the 128 columns leave no lane over).
+// first coefficient column of lane 0 of a strip
+__host__ __device__ __forceinline__ int strip_base_column(uint32_t strip, uint32_t strips, bool wide, int Tc)
+{
+	return wide ? 0 : ((int)strip * SNET - SORG - (((Tc & 1) && strip + 1 == strips) ? 1 : 0));
+}
+// does any lane of the strip need the border code (HEDGE variants)?  Shared with the host, which counts the
+// interior units of a launch with it.
+__host__ __device__ __forceinline__ bool strip_needs_border_code(uint32_t strip, uint32_t strips, bool wide, int Tc, int W, int wrap)
+{
+	const int c_base = strip_base_column(strip, strips, wide, Tc);
+	const bool left = (wrap != W_REPEAT) && (c_base < 0), right = (wrap != W_REPEAT) && (c_base + 128 > Tc);
+	const bool phantom = (W & 1) != 0;
+	return wide || left || right || (phantom && ((c_base + 128 >= Tc) || (wrap == W_REPEAT && c_base < 0)));
+}
+// does a row segment touch the top / bottom border (VEDGE variants)?  (the unrolled row loop may run up to 5 slots
+// past the segment and prefetches 2 further)
+__host__ __device__ __forceinline__ bool segment_needs_border_code(const StreamGeom& G, uint32_t seg, int Tr)
+{
+	int r_lo, r_hi, len;
+	segment_rows(G, seg, Tr, r_lo, r_hi, len);
+	return (r_lo < 3) || (r_lo + len + 12 > Tr);
+}
+
 __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips, bool wide, int lane, int Tc, int W, int wrap)
 {
 	LaneCols lc;
-	const int c_base = wide ? 0 : ((int)strip * SNET - SORG - (((Tc & 1) && strip + 1 == strips) ? 1 : 0));
+	const int c_base = strip_base_column(strip, strips, wide, Tc);
 	lc.c0 = c_base + 2 * lane;
 	lc.net = wide || ((lane >= 2) && (lane < 62));
 	lc.he.wrap = wrap;
@@ -537,8 +602,7 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	const bool phantom = (W & 1) != 0;
 	lc.he.drop_last = phantom && lc.he.last;
 	// (a half lane only exists where he.right is set; the phantom fix-ups also live in the border variants)
-	lc.hedge = wide || lc.he.left || lc.he.right ||
-	           (phantom && ((c_base + 128 >= Tc) || (wrap == W_REPEAT && c_base < 0)));  // some lane maps to the last pair
+	lc.hedge = strip_needs_border_code(strip, strips, wide, Tc, W, wrap);  // (phantom: some lane maps to the last pair)
 	if (wrap == W_REPEAT)
 		lc.cs = max(map_index(lc.c0, Tc, W_REPEAT) & ~1, 0);  // pairs stay together: c0 and Tc are even
 	else
@@ -826,7 +890,8 @@ struct FwdRaw<false>
 // chain: with the running prefetch every slot of such a wave waits for its own round trip to memory, with all
 // loads in flight at once the segment costs one round trip.  (A single pass over exactly N slots: the ring indices
 // of the column pipeline stay compile-time constants for any N.)
-template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE, int DEEP, bool CFAST = false>
+template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE, int DEEP, bool CFAST = false, int PF = 2, int LATE = 0,
+          bool MEMONLY = false>
 __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
                                                     const LaneCols& lc, int lane)
 {
@@ -841,26 +906,31 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	constexpr int P_STEP = (U8 && NPL == 2) ? 2 : 1;
 	const int c0 = lc.c0;
 
-	const int r_lo = (int)id.seg * (int)G.seg_rows;
-	const int r_hi = min(r_lo + (int)G.seg_rows, Tr);
+	int r_lo, r_hi, seg_len;
+	segment_rows(G, id.seg, Tr, r_lo, r_hi, seg_len);
+	(void)seg_len;
 
-	// sources
-	const uint8_t* img = nullptr;
-	const int16_t* src = nullptr;
-	uint64_t row_pitch;  // bytes (U8) or elements (int16)
+	// Sources, read through a raw buffer resource like the stores below: the wave-uniform origin of the tile
+	// (plane) is the resource's base, the lane's four samples are ONE register of byte offset for every load of the
+	// wave, and the row travels as the scalar offset -- no 64-bit vector address arithmetic per row.  (All reads are
+	// in range by construction; the plan keeps images and planes of 4 GiB and more away from these kernels.)
+	const uint8_t* src_base;
+	uint32_t row_pitch_b;  // bytes per row
 	if (U8)
 	{
-		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0 + lc.xs) * 4;
-		row_pitch = (uint64_t)P.img_pitch * 4;
+		src_base = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * 4;
+		row_pitch_b = P.img_pitch * 4u;
 	}
 	else
 	{
-		src = P.src + (P.src_tiled ? (uint64_t)id.image : inst) * P.src_inst_stride +
-		      (uint64_t)p_first * P.src_plane_stride + lc.xs;
+		const int16_t* src = P.src + (P.src_tiled ? (uint64_t)id.image : inst) * P.src_inst_stride + (uint64_t)p_first * P.src_plane_stride;
 		if (P.src_tiled)
 			src += (uint64_t)td.y0 * P.src_pitch + td.x0;
-		row_pitch = P.src_pitch;
+		src_base = reinterpret_cast<const uint8_t*>(src);
+		row_pitch_b = P.src_pitch * 2u;
 	}
+	const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_base), 0, (int)0xFFFFFFFFu, 0x00020000);
+	const uint32_t src_lane_off = (uint32_t)lc.xs * (U8 ? 4u : 2u);
 
 	// destinations.  Stream and LL stores go through raw buffer resources: a lane or a row that must not
 	// store gets an out-of-range offset and the hardware drops the write (scripts/probe_buffer_store.hip;
@@ -880,18 +950,19 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(
 	    ll_root, 0, (int)(uint32_t)(ll_left < 0xFFFFFFFFull ? ll_left : 0xFFFFFFFFull), RSRC_FLAGS);
 	const uint32_t ll_pitch = P.ll_out_stream ? (uint32_t)Tc : P.dst_pitch;
-	// Byte offsets of this lane's column pair in row 0: the per-lane part of a store address (voffset).  A lane that
-	// must not store carries an out-of-range one here, once and for all; the ROW part of the address is wave-uniform
-	// and travels as the scalar offset of the store, 0xFFFFFFFF for a row that must not be stored -- the hardware
-	// checks voffset + soffset (as a sum that does not wrap, scripts/probe_buffer_soffset.hip) against the end of
-	// the buffer.  No vector instruction is spent on addresses inside the row loop.
-	uint32_t ll_off[NPL], grp_off[NPL];
+	// Store addresses without vector arithmetic: the per-lane part (voffset) is the lane's column pair, ONE register
+	// for every store of the wave, out of range once and for all in a lane that must not store; everything else --
+	// plane, sub-band, row -- is wave-uniform and travels as the scalar offset of the store, 0xFFFFFFFF for a row
+	// that must not be stored.  The hardware checks voffset + soffset (as a sum that does not wrap,
+	// scripts/probe_buffer_soffset.hip) against the end of the buffer.
+	const uint32_t lane_off = store_lane ? (uint32_t)(c0 * 2) : OOB;
+	uint32_t ll_off[NPL], grp_off[NPL];  // scalar: byte offset of column 0, row 0 of this plane's LL / C sub-band
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 	{
 		const int pl = p_first + p * P_STEP;
-		grp_off[p] = store_lane ? (uint32_t)((P.grp_off[pl] + 1 + c0) * 2) : OOB;
-		ll_off[p] = store_lane ? (uint32_t)(((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) + c0) * 2) : OOB;
+		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1) * 2);
+		ll_off[p] = (uint32_t)((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) * 2);
 	}
 	const uint32_t nsub_b = (uint32_t)(nsub * 2);
 
@@ -919,10 +990,16 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		for (int par = 0; par < 2; par++)
 		{
 			const int y = min(2 * max(m, 0) + par, chh - 1);  // phantom last row = copy of the last row
-			if (U8)
-				raw.a[par] = *reinterpret_cast<const RawVec*>(img + (uint64_t)y * row_pitch);
+			const uint32_t row_off = (uint32_t)y * row_pitch_b;
+			if (MEMONLY && ((P.dbg & 64) || ((P.dbg & 128) && id.pg == 1)))  // bit 6: stores only; bit 7: one wave of a pair loads
+			{
+				raw.a[par] = RawVec{};
+				continue;
+			}
+			if constexpr (U8)
+				raw.a[par] = __builtin_bit_cast(RawVec, __builtin_amdgcn_raw_buffer_load_b128(rs_src, src_lane_off, row_off, AUX_FWD_PIXEL_LOAD));
 			else
-				raw.a[par] = *reinterpret_cast<const RawVec*>(src + (uint64_t)y * row_pitch);
+				raw.a[par] = __builtin_bit_cast(RawVec, __builtin_amdgcn_raw_buffer_load_b64(rs_src, src_lane_off, row_off, 0));
 		}
 	};
 
@@ -936,10 +1013,46 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			__builtin_amdgcn_raw_buffer_store_b32(0u, rs_stream, OOB, 0, 0);
 	};
 	// one row slot: K = unroll position (ring indices of the column pipeline), v = slot, raw = its two fetched rows
-	auto do_slot = [&](auto kc, const int v, const Raw& raw) {
+	// (raw_consumed() is called as soon as the slot's fetched rows have been turned into samples: see LATE below)
+	auto do_slot = [&](auto kc, const int v, const Raw& raw, auto&& raw_consumed) {
 			constexpr int K = decltype(kc)::value;
 			const bool zero_row = VEDGE && (wrap == W_ZERO) && ((unsigned)v >= (unsigned)Tr);
 
+			if constexpr (MEMONLY)
+			{
+				// measurement aid (AKO_HIP_DBG bit 4): the slot's loads and stores with no arithmetic between them --
+				// what the memory system alone takes for this access pattern (the output is garbage)
+				raw_consumed();
+				const int r = v - 3;
+				const bool row_ok = (r >= r_lo) && (r < r_hi) && !(P.dbg & 32);  // bit 5: loads only
+				const uint32_t rr = (uint32_t)r;
+				const uint32_t row_grp = rr * (uint32_t)Tc * 2u, row_ll = rr * ll_pitch * 2u;
+				if (P.dbg & 256)  // bit 8: the same bytes as ONE 16-byte-per-lane store per plane (what wider stores would cost)
+				{
+					typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+					for (int p = 0; p < NPL; p++)
+					{
+						const uint32_t so = row_ok ? (rr * G.strips + id.strip) * 2048u + (uint32_t)p * 1024u : OOB;
+						__builtin_amdgcn_raw_buffer_store_b128(u32x4{raw.a[0].x, raw.a[0].y, raw.a[1].x, raw.a[1].y}, rs_stream, (uint32_t)lane * 16u, so, 0);
+					}
+					return;
+				}
+#pragma unroll
+				for (int p = 0; p < NPL; p++)
+				{
+					uint32_t a, b, c, d;
+					if constexpr (U8)
+						a = raw.a[p].x, b = raw.a[p].y, c = raw.a[p].z, d = raw.a[p].w;
+					else
+						a = raw.a[0].x, b = raw.a[0].y, c = raw.a[1].x, d = raw.a[1].y;
+					__builtin_amdgcn_raw_buffer_store_b32(a, rs_ll, lane_off, row_ok ? ll_off[p] + row_ll : OOB, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(b, rs_stream, lane_off, row_ok ? grp_off[p] + row_grp : OOB, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(c, rs_stream, lane_off, row_ok ? grp_off[p] + row_grp + nsub_b : OOB, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(d, rs_stream, lane_off, row_ok ? grp_off[p] + row_grp + 2u * nsub_b : OOB, 0);
+				}
+				return;
+			}
 			V smp[2][NPL][4];
 #pragma unroll
 			for (int par = 0; par < 2; par++)
@@ -978,6 +1091,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					for (int p = 0; p < NPL; p++)
 						smp[par][p][0] = smp[par][p][2], smp[par][p][1] = smp[par][p][3];
 			}
+			raw_consumed();
 
 			const int r = v - 3;
 			uint32_t w_ll[NPL], w_c[NPL], w_b[NPL], w_d[NPL];
@@ -1002,16 +1116,18 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			{
 				const bool row_ok = (r >= r_lo) && (r < r_hi);  // wave-uniform
 				const uint32_t rr = (uint32_t)r;
-				const uint32_t row_grp = row_ok ? rr * (uint32_t)Tc * 2u : OOB;
-				const uint32_t row_ll = row_ok ? rr * ll_pitch * 2u : OOB;
-				const uint32_t row_b = row_ok ? row_grp + nsub_b : OOB, row_d = row_ok ? row_grp + 2u * nsub_b : OOB;
+				const uint32_t row_grp = rr * (uint32_t)Tc * 2u, row_ll = rr * ll_pitch * 2u;
 #pragma unroll
 				for (int p = 0; p < NPL; p++)
 				{
-					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, ll_off[p], row_ll, 0);
-					__builtin_amdgcn_raw_buffer_store_b32(w_c[p], rs_stream, grp_off[p], row_grp, 0);
-					__builtin_amdgcn_raw_buffer_store_b32(w_b[p], rs_stream, grp_off[p], row_b, 0);
-					__builtin_amdgcn_raw_buffer_store_b32(w_d[p], rs_stream, grp_off[p], row_d, 0);
+					const uint32_t s_ll = row_ok ? ll_off[p] + row_ll : OOB;
+					const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
+					const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
+					const uint32_t s_d = row_ok ? grp_off[p] + row_grp + 2u * nsub_b : OOB;
+					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, lane_off, s_ll, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_c[p], rs_stream, lane_off, s_c, AUX_FWD_STREAM_STORE);
+					__builtin_amdgcn_raw_buffer_store_b32(w_b[p], rs_stream, lane_off, s_b, AUX_FWD_STREAM_STORE);
+					__builtin_amdgcn_raw_buffer_store_b32(w_d[p], rs_stream, lane_off, s_d, AUX_FWD_STREAM_STORE);
 				}
 			}
 	};
@@ -1021,22 +1137,49 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		(void)n_slots, (void)phantom_stores;
 		Raw all[DEEP];
 		static_for<DEEP>([&](auto kc) { fetch(v_begin + decltype(kc)::value, all[decltype(kc)::value]); });
-		static_for<DEEP>([&](auto kc) { do_slot(kc, v_begin + decltype(kc)::value, all[decltype(kc)::value]); });
+		static_for<DEEP>([&](auto kc) { do_slot(kc, v_begin + decltype(kc)::value, all[decltype(kc)::value], [] {}); });
 	}
-	else
+	else if constexpr (LATE > 0)
 	{
-		Raw ring[3];
-		fetch(v_begin, ring[0]);
-		phantom_stores();
-		fetch(v_begin + 1, ring[1]);
-		phantom_stores();
+		// LATE row slots ahead with a ring of LATE entries: the fetch for slot v + LATE is issued right after slot v's
+		// rows have been decoded into samples, into the registers they just left (one entry fewer than a ring that
+		// is refilled at the top of the slot).  A wave's loads in flight are what bounds these kernels -- memory
+		// latency under load is several microseconds -- so the ring is as deep as the register budget allows.
+		static_assert(6 % LATE == 0, "the ring index must repeat with the unrolled row loop");
+		Raw ring[LATE];
+		static_for<LATE>([&](auto kc) {
+			fetch(v_begin + decltype(kc)::value, ring[decltype(kc)::value]);
+			phantom_stores();
+		});
 		for (int base = 0; base < n_slots; base += 6)
 		{
 			static_for<6>([&](auto kc) {
 				constexpr int K = decltype(kc)::value;
 				const int v = v_begin + base + K;
-				fetch(v + 2, ring[(K + 2) % 3]);  // prefetch two slots ahead (clamped rows: always in range)
-				do_slot(kc, v, ring[K % 3]);
+				do_slot(kc, v, ring[K % LATE], [&] { fetch(v + LATE, ring[K % LATE]); });
+			});
+		}
+	}
+	else
+	{
+		// PF row slots are fetched ahead of the one being worked on (2; 1 in the kernels that trade the third ring
+		// entry's registers for a fourth wave per SIMD)
+		static_assert(PF == 1 || PF == 2, "prefetch distance");
+		Raw ring[PF + 1];
+		fetch(v_begin, ring[0]);
+		phantom_stores();
+		if constexpr (PF == 2)
+		{
+			fetch(v_begin + 1, ring[1]);
+			phantom_stores();
+		}
+		for (int base = 0; base < n_slots; base += 6)
+		{
+			static_for<6>([&](auto kc) {
+				constexpr int K = decltype(kc)::value;
+				const int v = v_begin + base + K;
+				fetch(v + PF, ring[(K + PF) % (PF + 1)]);  // prefetch (clamped rows: always in range)
+				do_slot(kc, v, ring[K % (PF + 1)], [] {});
 			});
 		}
 	}
@@ -1051,9 +1194,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 	const int lane = threadIdx.x & 63;
 	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	// segment touches the top / bottom border (or wraps over it): needs the row boundary code
-	const int r_lo = (int)id.seg * (int)G.seg_rows;
-	// (the unrolled row loop may run up to 5 slots past the segment and prefetches 2 further)
-	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	// u8 side: the usual colour mode gets straight-line pixel decoding (decode_pixels_ycocg)
 	const bool cfast = U8 && (P.color == C_YCOCG || P.color == C_YCOCG_Q) && P.discard == 0;
 #define AKO_FWD_BODY(H, V)                                                                       \
@@ -1087,6 +1228,77 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P,
 #undef AKO_FWD_BODY
 }
 
+// The u8 level kernel (level 0 of RGBA images).  The streaming kernels are bound by how many waves a SIMD can
+// interleave (one wave issues a VALU instruction every ~5 cycles at best, and nothing else hides the latencies of
+// the unrolled row slots), so this kernel is held to 128 VGPRs = 4 waves per SIMD: the interior body and the
+// left / right border body fit (prefetch distance 1 instead of 2, every address a scalar offset on one per-lane
+// register), the top / bottom border bodies -- three row segments in a hundred -- spill a few dozen registers to
+// scratch and are the only ones that do.
+#ifndef AKO_U8_RING
+#define AKO_U8_RING 2
+#endif
+#ifndef AKO_U8_WAVES
+#define AKO_U8_WAVES 4
+#endif
+constexpr int U8_RING = AKO_U8_RING;  // row slots the u8 forward kernel fetches ahead (2, 3 or 6)
+
+// measurement aid: the interior body's loads and stores without its arithmetic, every unit (AKO_HIP_DBG bit 4)
+__global__ __launch_bounds__(THREADS) void k_forward_stream_u8_memonly(const LevelParams P, const StreamGeom G)
+{
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	forward_stream_body<K_DD137, 2, true, false, false, true, 0, true, 2, U8_RING, true>(P, G, id, lc, lane);
+}
+
+__global__ __launch_bounds__(THREADS) void k_forward_stream_i16_memonly(const LevelParams P, const StreamGeom G)
+{
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	forward_stream_body<K_DD137, 1, false, false, false, true, 0, false, 2, 0, true>(P, G, id, lc, lane);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_forward_stream_u8(const LevelParams P, const StreamGeom G)
+{
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	// the usual colour mode gets straight-line pixel decoding (decode_pixels_ycocg)
+	const bool cfast = (P.color == C_YCOCG || P.color == C_YCOCG_Q) && P.discard == 0;
+#define AKO_FWD_U8(H, V)                                                                               \
+	do                                                                                                 \
+	{                                                                                                  \
+		if (cfast)                                                                                     \
+			forward_stream_body<KIND, 2, true, false, H, V, 0, true, 2, U8_RING>(P, G, id, lc, lane);             \
+		else                                                                                           \
+			forward_stream_body<KIND, 2, true, false, H, V, 0, false, 2, U8_RING>(P, G, id, lc, lane);            \
+	} while (0)
+	if (__builtin_expect(vedge, 0))
+	{
+		if (lc.hedge)
+			AKO_FWD_U8(true, true);
+		else
+			AKO_FWD_U8(false, true);
+	}
+	else
+	{
+		if (lc.hedge)
+			AKO_FWD_U8(true, false);
+		else
+			AKO_FWD_U8(false, false);
+	}
+#undef AKO_FWD_U8
+}
+
 // ---------------------------------------------------------------------------------------------
 // Inverse.  NPL = planes handled by one wave: 2 with U8 (the workgroup is then exactly one PAIR of
 // waves working on the same strip and segment, see the file header), 1 on int16 planes.
@@ -1113,7 +1325,7 @@ struct InvRaw
 constexpr float OPT_INPUT_BOUND = 3560.0f;
 constexpr float OPT_OUTPUT_BOUND = 10921.0f;
 
-template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE, int DEEP>
+template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE, int DEEP, int PF = 2>
 __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
                                                     const LaneCols& lc, int lane, uint4 (*xbuf)[2][2][64])
 {
@@ -1129,29 +1341,30 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	const int p_first = U8 ? 2 * pair : (int)id.pg;
 	const int c0 = lc.c0;
 
-	const int r_lo = (int)id.seg * (int)G.seg_rows;
-	const int r_hi = min(r_lo + (int)G.seg_rows, Tr);
+	int r_lo, r_hi, seg_len;
+	segment_rows(G, id.seg, Tr, r_lo, r_hi, seg_len);
+	(void)seg_len;
 
 	const int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
 	const uint64_t nsub = (uint64_t)Tc * Tr;
-	const int16_t* ll_base[NPL];
-	const int16_t* grp_base[NPL];
+	// Loads through raw buffer resources, as in the forward kernels: ONE register of byte offset per lane (its
+	// column pair) for every load of the wave; plane, sub-band and row travel as the scalar offset.
+	constexpr int RSRC_FLAGS = 0x00020000;
+	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(tile_stream), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
+	const int16_t* ll_root = P.ll_in_stream ? tile_stream : (P.src + inst * P.src_inst_stride);
+	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(ll_root), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
+	const uint32_t ll_pitch = P.ll_in_stream ? (uint32_t)Tc : P.src_pitch;
+	const uint32_t lane_in_off = (uint32_t)lc.cs * 2u;
+	const uint32_t nsub_b = (uint32_t)(nsub * 2);
+	uint32_t ll_off[NPL], grp_off[NPL];  // scalar: byte offset of column 0, row 0 of this plane's LL / C sub-band
 	int qv[NPL];
-	uint32_t ll_pitch = (uint32_t)Tc;
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 	{
 		const int pl = p_first + p;
-		const int16_t* grp = tile_stream + P.grp_off[pl];
-		qv[p] = grp[0];  // the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116)
-		grp_base[p] = grp + 1 + lc.cs;
-		if (P.ll_in_stream)
-			ll_base[p] = tile_stream + P.lp_off[pl] + lc.cs;
-		else
-		{
-			ll_base[p] = P.src + inst * P.src_inst_stride + (uint64_t)pl * P.src_plane_stride + lc.cs;
-			ll_pitch = P.src_pitch;
-		}
+		qv[p] = tile_stream[P.grp_off[pl]];  // the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116)
+		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1) * 2);
+		ll_off[p] = (uint32_t)((P.ll_in_stream ? P.lp_off[pl] : (uint64_t)pl * P.src_plane_stride) * 2);
 	}
 
 	// destination
@@ -1160,7 +1373,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	uint64_t out_pitch;
 	if (U8)
 	{
-		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0 + 2 * c0) * 4;
+		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * 4;  // tile origin
 		out_pitch = (uint64_t)P.img_pitch * 4;
 	}
 	else
@@ -1174,6 +1387,12 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	// the output width is 2 * Tc here (level widths that are multiples of 4), rows may be odd in number
 	const bool store_lane = lc.net && (c0 >= 0) && (c0 < Tc);
 	(void)ow;
+	// u8 side: the pixel row goes out through a raw buffer store as well -- the lane's four pixels are a byte offset
+	// that is out of range in a lane that must not store, the row is the scalar offset (0xFFFFFFFF: row dropped)
+	constexpr uint32_t OOB = 0xFFFFFFFFu;
+	const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(U8 ? (void*)img : (void*)nullptr, 0, U8 ? (int)0xFFFFFFFFu : 0, RSRC_FLAGS);
+	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * c0) * 4u : OOB;
+	(void)rs_img, (void)px_lane_off;
 
 	VInv<V> st[NPL][4];
 #pragma unroll
@@ -1185,14 +1404,15 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	using Raw = InvRaw<NPL>;
 	auto fetch = [&](int v, Raw& raw) {
 		const int m = max(VEDGE ? map_index(v, Tr, wrap) : v, 0);
+		const uint32_t row_g = (uint32_t)m * (uint32_t)Tc * 2u, row_l = (uint32_t)m * ll_pitch * 2u;
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
 		{
-			const int16_t* g = grp_base[p] + (uint64_t)m * Tc;
-			raw.ll[p] = *reinterpret_cast<const uint32_t*>(ll_base[p] + (uint64_t)m * ll_pitch);
-			raw.c[p] = *reinterpret_cast<const uint32_t*>(g);
-			raw.b[p] = *reinterpret_cast<const uint32_t*>(g + nsub);
-			raw.d[p] = *reinterpret_cast<const uint32_t*>(g + 2 * nsub);
+			const uint32_t g = grp_off[p] + row_g;
+			raw.ll[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_ll, lane_in_off, ll_off[p] + row_l, 0);
+			raw.c[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g, AUX_INV_STREAM_LOAD);
+			raw.b[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + nsub_b, AUX_INV_STREAM_LOAD);
+			raw.d[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + 2u * nsub_b, AUX_INV_STREAM_LOAD);
 		}
 	};
 
@@ -1210,10 +1430,20 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 			{
 				// columns: 0,1 = row low-pass columns c0, c1 (LL over C); 2,3 = row high-pass (B over D)
 				V lpv[4], hpv[4];
-				lpv[0] = (V)lo16(raw.ll[p]), lpv[1] = (V)hi16(raw.ll[p]);
-				lpv[2] = (V)lo16(raw.b[p]), lpv[3] = (V)hi16(raw.b[p]);
-				hpv[0] = (V)lo16(raw.c[p]), hpv[1] = (V)hi16(raw.c[p]);
-				hpv[2] = (V)lo16(raw.d[p]), hpv[3] = (V)hi16(raw.d[p]);
+				if constexpr (OPT)  // float pipe: sign-extending word selects on the conversions (unpack2_f)
+				{
+					unpack2_f(raw.ll[p], lpv[0], lpv[1]);
+					unpack2_f(raw.b[p], lpv[2], lpv[3]);
+					unpack2_f(raw.c[p], hpv[0], hpv[1]);
+					unpack2_f(raw.d[p], hpv[2], hpv[3]);
+				}
+				else
+				{
+					lpv[0] = (V)lo16(raw.ll[p]), lpv[1] = (V)hi16(raw.ll[p]);
+					lpv[2] = (V)lo16(raw.b[p]), lpv[3] = (V)hi16(raw.b[p]);
+					hpv[0] = (V)lo16(raw.c[p]), hpv[1] = (V)hi16(raw.c[p]);
+					hpv[2] = (V)lo16(raw.d[p]), hpv[3] = (V)hi16(raw.d[p]);
+				}
 				const int q = qv[p];
 				if (q > 1)  // lifting.c:30-40 (int16 wrap on the exact pipe)
 				{
@@ -1290,7 +1520,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				}
 				__syncthreads();
 				const int y = 2 * r + pair;
-				if (store_row && y < oh)  // phantom last row dropped (lifting.c:112,141)
+				const bool row_ok = (r >= r_lo) && (r < r_hi) && (y < oh);  // wave-uniform; phantom last row dropped (lifting.c:112,141)
+				if (row_ok)
 				{
 					const uint4 g0 = xbuf[K & 1][pair][0][lane], g1 = xbuf[K & 1][pair][1][lane];
 					const float his0[4] = {__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w)};
@@ -1316,13 +1547,13 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 							px[k] = pixel_u8x4(rr, gg, bb, his1[k]);
 						}
 					}
+					const uint32_t s_row = (uint32_t)y * (uint32_t)out_pitch;
+					typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+					typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 					if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
-					{
-						uint32_t* o = reinterpret_cast<uint32_t*>(img + (uint64_t)y * out_pitch);
-						o[0] = px[0], o[1] = px[1], o[2] = px[2];
-					}
+						__builtin_amdgcn_raw_buffer_store_b96(u32x3{px[0], px[1], px[2]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
 					else
-						*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
+						__builtin_amdgcn_raw_buffer_store_b128(u32x4{px[0], px[1], px[2], px[3]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
 				}
 			}
 			else if constexpr (U8)
@@ -1355,13 +1586,14 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
 						        ((uint32_t)sat8((int)v3) << 24);
 					}
+					uint8_t* row = img + (uint64_t)y * out_pitch + (int64_t)(2 * c0) * 4;
 					if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
 					{
-						uint32_t* o = reinterpret_cast<uint32_t*>(img + (uint64_t)y * out_pitch);
+						uint32_t* o = reinterpret_cast<uint32_t*>(row);
 						o[0] = px[0], o[1] = px[1], o[2] = px[2];
 					}
 					else
-						*reinterpret_cast<uint4*>(img + (uint64_t)y * out_pitch) = make_uint4(px[0], px[1], px[2], px[3]);
+						*reinterpret_cast<uint4*>(row) = make_uint4(px[0], px[1], px[2], px[3]);
 				}
 			}
 			else if (store_row)
@@ -1396,16 +1628,18 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	}
 	else
 	{
-		Raw ring[3];
+		static_assert(PF == 1 || PF == 2, "prefetch distance");
+		Raw ring[PF + 1];
 		fetch(v_begin, ring[0]);
-		fetch(v_begin + 1, ring[1]);
+		if constexpr (PF == 2)
+			fetch(v_begin + 1, ring[1]);
 		for (int base = 0; base < n_slots; base += 6)
 		{
 			static_for<6>([&](auto kc) {
 				constexpr int K = decltype(kc)::value;
 				const int v = v_begin + base + K;
-				fetch(v + 2, ring[(K + 2) % 3]);
-				do_slot(kc, v, ring[K % 3]);
+				fetch(v + PF, ring[(K + PF) % (PF + 1)]);
+				do_slot(kc, v, ring[K % (PF + 1)]);
 			});
 		}
 	}
@@ -1432,8 +1666,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 		return;  // U8: units come in pairs and the workgroup is one pair, so both waves leave together
 	const int lane = threadIdx.x & 63;
 	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
-	const int r_lo = (int)id.seg * (int)G.seg_rows;
-	const bool vedge = (r_lo < 3) || (r_lo + (int)G.seg_rows + 12 > (int)P.sub_h);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	if (lc.hedge)
 	{
 		if (vedge)
@@ -1447,6 +1680,39 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 			inverse_stream_body<KIND, NPL, U8, OPT, false, true, DEEP>(P, G, id, lc, lane, xbuf);
 		else
 			inverse_stream_body<KIND, NPL, U8, OPT, false, false, DEEP>(P, G, id, lc, lane, xbuf);
+	}
+}
+
+// The u8 inverse level kernel at 4 waves per SIMD (see k_forward_stream_u8): the workgroup is one pair of waves.
+// OPT = optimistic fp32 pipeline; the exact re-run behind it (OPT = false) returns at once unless flagged.
+template <int KIND, bool OPT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_inverse_stream_u8(const LevelParams P, const StreamGeom G)
+{
+	__shared__ uint4 xbuf[2][2][2][64];  // [slot parity][destination wave of the pair][plane][lane]
+	if (!OPT && P.ovf_flag != nullptr)
+	{
+		if (__builtin_amdgcn_readfirstlane(*(volatile const int32_t*)P.ovf_flag) == 0)
+			return;
+	}
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;  // units come in pairs and the workgroup is one pair, so both waves leave together
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	if (__builtin_expect(vedge, 0))
+	{
+		if (lc.hedge)
+			inverse_stream_body<KIND, 2, true, OPT, true, true, 0, 2>(P, G, id, lc, lane, xbuf);
+		else
+			inverse_stream_body<KIND, 2, true, OPT, false, true, 0, 2>(P, G, id, lc, lane, xbuf);
+	}
+	else
+	{
+		if (lc.hedge)
+			inverse_stream_body<KIND, 2, true, OPT, true, false, 0, 2>(P, G, id, lc, lane, xbuf);
+		else
+			inverse_stream_body<KIND, 2, true, OPT, false, false, 0, 2>(P, G, id, lc, lane, xbuf);
 	}
 }
 

@@ -24,6 +24,32 @@
 #include <string.h>
 #include <unistd.h>
 
+/* AKO_HIP_TRACE=1: wall-clock of the stages of the drivers on stderr (where a call's time goes) */
+#include <time.h>
+static double now_ms(void)
+{
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
+}
+static int tracing(void)
+{
+	static int on = -1;
+	if (on < 0)
+		on = (getenv("AKO_HIP_TRACE") != NULL);
+	return on;
+}
+#define TRACE(label, since)                                                                     \
+	do                                                                                          \
+	{                                                                                           \
+		if (tracing())                                                                          \
+		{                                                                                       \
+			const double t_ = now_ms();                                                         \
+			fprintf(stderr, "libako trace: %-28s %8.3f ms\n", (label), t_ - (since));           \
+			(since) = t_;                                                                       \
+		}                                                                                       \
+	} while (0)
+
 static void fire(const struct akoCallbacks* c, size_t tile, size_t total, enum akoEvent e)
 {
 	if (c->events != NULL)
@@ -289,6 +315,52 @@ static void tokenize_tiles(struct tile_job* jobs, size_t count)
 	tile_worker(&pool);
 	for (size_t k = 0; k < started; k++)
 		pthread_join(th[k], NULL);
+}
+
+/* ---- first touch of a large result buffer, off the critical path ---------------------------------------------
+ * The decoded image goes into memory fresh from the caller's malloc.  Fresh pages are mapped on first touch, and
+ * for a 268 MB image that costs the copy back from the device more than the copy itself (65536 page faults in the
+ * copying thread).  The pages are touched here instead, by a few helper threads, while the caller's thread is still
+ * busy parsing the entropy-coded input; the buffer is the library's own until it is returned, so writing zeros
+ * into it is invisible. */
+#define TOUCH_THREADS 4
+struct toucher
+{
+	uint8_t* base;
+	size_t bytes;
+	pthread_t thread;
+	int started;
+};
+static void* touch_main(void* arg)
+{
+	struct toucher* t = arg;
+	for (size_t off = 0; off < t->bytes; off += 4096)
+		((volatile uint8_t*)t->base)[off] = 0;
+	return NULL;
+}
+static void touch_begin(struct toucher* ts, uint8_t* base, size_t bytes)
+{
+	memset(ts, 0, TOUCH_THREADS * sizeof *ts);
+	if (bytes < ((size_t)16 << 20))
+		return;
+	const size_t part = ((bytes / TOUCH_THREADS) + 4095) & ~(size_t)4095;
+	for (size_t k = 0; k < TOUCH_THREADS; k++)
+	{
+		const size_t lo = k * part;
+		if (lo >= bytes)
+			break;
+		ts[k].base = base + lo, ts[k].bytes = (lo + part < bytes) ? part : bytes - lo;
+		ts[k].started = (pthread_create(&ts[k].thread, NULL, touch_main, &ts[k]) == 0);
+	}
+}
+static void touch_end(struct toucher* ts)
+{
+	for (size_t k = 0; k < TOUCH_THREADS; k++)
+		if (ts[k].started)
+		{
+			pthread_join(ts[k].thread, NULL);
+			ts[k].started = 0;
+		}
 }
 
 /* ---- several devices: a tiled image split into bands of whole tile rows -------------------------------------
@@ -711,6 +783,8 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	memset(&tokens, 0, sizeof tokens);
 	struct tile_job* jobs = NULL;
 	size_t n_jobs = 0;
+	struct toucher touchers[TOUCH_THREADS];
+	memset(touchers, 0, sizeof touchers);
 
 	const struct akoCallbacks cb = (c != NULL) ? *c : akoDefaultCallbacks();
 	if (cb.malloc == NULL || cb.realloc == NULL || cb.free == NULL)
@@ -868,11 +942,13 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	if (st.compression != AKO_COMPRESSION_NONE && !(kg_env != NULL && strcmp(kg_env, "host") == 0) &&
 	    stream_bytes / 2 <= 0xFFFFFFF0ull)
 	{
+		double t_trace = tracing() ? now_ms() : 0.0;
 		if ((image = cb.malloc(image_w * image_h * channels)) == NULL)
 		{
 			status = AKO_NO_ENOUGH_MEMORY;
 			goto failure;
 		}
+		touch_begin(touchers, image, image_w * image_h * channels);
 		memset(&tokens, 0, sizeof tokens);
 
 		/* several tiles: they are parsed on worker threads, a bounded WINDOW of tiles at a time (host memory stays
@@ -968,6 +1044,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 			cursor += (size_t)block + 4;
 			if (t + 1 == tiles)
 			{
+				TRACE("decode: parse bit-streams", t_trace);
 				const int rc = akoHipKagariExpand(plan, tokens.literals, tokens.n_literals,
 				                                  (const struct akoHipKagariRun*)tokens.runs, tokens.n_runs, NULL, 0);
 				if (rc != 0)
@@ -983,7 +1060,10 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 				fire(&cb, t, tiles, AKO_EVENT_WAVELET_START);
 			if (t + 1 == tiles)
 			{
+				TRACE("decode: upload + expand runs", t_trace);
+				touch_end(touchers);
 				const int rc = akoHipDecodeDownload(plan, image);
+				TRACE("decode: transform + download", t_trace);
 				if (rc != 0)
 				{
 					status = (enum akoStatus)rc;
@@ -1087,6 +1167,7 @@ decoded:
 	return image;
 
 failure:
+	touch_end(touchers); /* nobody may still write into the image when it is freed */
 	akoHostKagariTokensFree(&tokens);
 	if (jobs != NULL)
 	{

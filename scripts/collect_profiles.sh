@@ -4,7 +4,7 @@
 #   the PMC traffic passes (scripts/collect_traffic.sh) and the SQ counter pass (scripts/collect_sq.sh).
 # usage (GPU box):  bash scripts/collect_profiles.sh <tag>      -> gpurun_out/profiles_<tag>/
 set -e
-TAG=${1:-r1}
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"

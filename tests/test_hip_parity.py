@@ -251,7 +251,7 @@ def test_level_widths_not_multiples_of_4(po, path_mode):
                 d_img = torch.from_numpy(nrng.integers(0, 256, (1, 70, ww, 4), dtype=np.uint8)).cuda()
                 plan.decode(plan.encode(d_img))
                 plan.synchronize()
-                assert plan.kernel_records(False)[0]["name"] == "fwd_stream_dd137_u8", ww
+                assert plan.kernel_records(False)[0]["name"].startswith("fwd_stream_dd137_u8"), ww   # (+ "_borders")
                 assert plan.kernel_records(True)[-1]["name"].startswith("inv_stream_dd137_u8"), ww
 
 
