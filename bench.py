@@ -434,32 +434,6 @@ def main():
         kern_ms = sum(a["ms"] for a in agg.values()) / args.steps
         total_alg_bytes = (3 * ch * pixels * 2) if not planes else (8 * pixels)
         copy_gbps = copy_bandwidth(torch, dev)
-        # What the memory system alone takes for the forward level-0 kernel's access pattern: the same launch with
-        # every load and store of the kernel and NO arithmetic between them (AKO_HIP_DBG bit 4 selects that
-        # measurement kernel when a plan is created; its output is garbage and goes to buffers of its own).
-        memory_pattern = None
-        if not planes and ch == 4:
-            old_dbg = os.environ.get("AKO_HIP_DBG")
-            os.environ["AKO_HIP_DBG"] = "16"
-            try:
-                with api.Plan(s, ch, w, h, batch=batch, device=local_rank) as pm:
-                    scratch_str = pm.new_streams()
-                    pm.encode(d_img, scratch_str)
-                    pm.synchronize()
-                    pm.set_profiling(True)
-                    for _ in range(10):
-                        pm.encode(d_img, scratch_str)
-                    pm.synchronize()
-                    ms = sorted(r["ms"] for r in pm.kernel_records(False) if r["level"] == 0 and "_u8" in r["name"])
-                    if ms:
-                        memory_pattern = {"kernel": "fwd_stream level 0: its loads and stores, no arithmetic",
-                                          "ms": round(ms[len(ms) // 2], 4), "min_ms": round(ms[0], 4)}
-                    del scratch_str
-            finally:
-                if old_dbg is None:
-                    os.environ.pop("AKO_HIP_DBG", None)
-                else:
-                    os.environ["AKO_HIP_DBG"] = old_dbg
         out = {
             "metric": "Mpixels/s encode+decode (DD137, q=16)",
             "value": round(value, 2),
@@ -496,7 +470,6 @@ def main():
                 "algorithmic_bytes_per_launch": dom["bytes"],
                 "measured_copy_GBps": round(copy_gbps, 1),
                 "frac_of_measured_copy": round(achieved / copy_gbps, 4),
-                "memory_pattern": memory_pattern,
                 "note": ("kernel durations: HIP events on the kernel's own stream inside bench.py. With several steps in "
                          "flight the kernels of different steps share the chip, so 'achieved' is taken from the passes "
                          "bench.py runs with ONE step in flight right after the timed region (same plan, same buffers; "

@@ -10,6 +10,6 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -- python3 "$R/bench.py" --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$C.json" 2> "$OUT/$C.err" || { tail -5 "$OUT/$C.err"; exit 1; }
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -- python3 "$R/scripts/traffic_step.py" > "$OUT/$C.json" 2> "$OUT/$C.err" || { tail -5 "$OUT/$C.err"; exit 1; }
 done
 python3 "$R/scripts/parse_traffic.py" "$OUT" "$WL"
