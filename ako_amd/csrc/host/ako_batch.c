@@ -263,7 +263,7 @@ AKO_API akoHipBatch* akoHipBatchCreate(const int* devices, size_t n_devices, siz
 	if (devices == NULL || n_devices == 0)
 		devices = &dev0, n_devices = 1;
 	if (lanes_per_device == 0)
-		lanes_per_device = 3;
+		lanes_per_device = 6; /* 3840x2160 RGBA on one MI355X: 2 lanes 6.7, 4 lanes 9.1, 6 lanes 12.2 Gpx/s (link bound 13.8) */
 	if (settings == NULL || channels == 0 || image_w == 0 || image_h == 0 || n_devices > 64 || lanes_per_device > 16)
 	{
 		st = AKO_INVALID_INPUT;

@@ -189,7 +189,7 @@ void akoHipThreadRelease(void);
  * byte-identical to akoEncodeExt's for the same image and settings.
  *
  * akoHipBatchCreate   devices: n_devices HIP device indices (NULL: device 0; a device may appear more than once);
- *                     lanes_per_device 0 = default (3)
+ *                     lanes_per_device 0 = default (6)
  * akoHipEncodeBatch   images[i]: image_w * image_h * channels bytes each.  out_blobs[i] / out_sizes[i]: a malloc'ed
  *                     blob per image (release with akoDefaultFree), NULL / 0 where out_status[i] != AKO_OK
  *                     (out_status may be NULL).  Returns 0 when every image was encoded
