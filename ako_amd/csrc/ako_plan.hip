@@ -130,6 +130,11 @@ struct Tuning
 	bool staged = true;    // AKO_HIP_STAGED=0: no planar staging of 1-3 / 5+ channel u8 images
 	bool deep = true;      // AKO_HIP_DEEP=0: small levels keep the running two-slot prefetch
 	int u8_waves = 0;      // AKO_HIP_U8_WAVES: waves a u8 level launch aims at (0 = two rounds of resident waves)
+	int lockstep = 3;      // AKO_HIP_LOCKSTEP: StreamGeom::lockstep (bit 0 barrier every six slots, bit 1 strip-major units)
+	int fwd_pairs = 2;     // AKO_HIP_FWD_PAIRS: pairs of waves (= neighbouring strips) per workgroup of the u8 forward kernel
+	int inv_pairs = 2;     // AKO_HIP_INV_PAIRS: same for the u8 inverse kernel (1, 2 or 4)
+	bool fuse = false;     // AKO_HIP_FUSE=1: forward level 1 inside the level-0 strip walk (k_forward_fused_u8) instead of a launch of
+	                       // its own.  Bit-exact and parity-tested, but off by default: measured slower
 	uint32_t dbg = 0;      // AKO_HIP_DBG bits (kernel side experiments)
 
 	static Tuning from_env()
@@ -151,6 +156,14 @@ struct Tuning
 		t.staged = num("AKO_HIP_STAGED", 1) != 0;
 		t.deep = num("AKO_HIP_DEEP", 1) != 0;
 		t.u8_waves = num("AKO_HIP_U8_WAVES", 0);
+		t.lockstep = num("AKO_HIP_LOCKSTEP", 3) & 3;
+		t.fwd_pairs = num("AKO_HIP_FWD_PAIRS", 2);
+		t.inv_pairs = num("AKO_HIP_INV_PAIRS", 2);
+		if (t.fwd_pairs != 1 && t.fwd_pairs != 4)
+			t.fwd_pairs = 2;
+		if (t.inv_pairs != 1 && t.inv_pairs != 4)
+			t.inv_pairs = 2;
+		t.fuse = num("AKO_HIP_FUSE", 0) != 0;
 		t.dbg = (uint32_t)num("AKO_HIP_DBG", 0);
 		return t;
 	}
@@ -420,6 +433,7 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 	StreamGeom G;
 	G.strips = (L.tw + SNET - 1) / SNET;
 	G.wide = 0;
+	G.lockstep = (uint32_t)pl->tune.lockstep;
 	G.edge_rows = 0;
 	// 121..128 coefficient columns (an even number): one strip without halo lanes instead of two
 	if (L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && pl->tune.wide)
@@ -454,6 +468,48 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		G.edge_rows = EDGE_ROWS;
 		G.segs = 3 + (L.th - 3 * EDGE_ROWS + seg_rows - 1) / seg_rows;
 	}
+	return G;
+}
+
+// Forward levels 0 and 1 of a u8 RGBA plan in ONE strip walk (k_forward_fused_u8): shapes without phantom columns or
+// rows at either level, CLAMP or ZERO borders (the level-1 row pass of the fused kernel implements those two), the
+// same wavelet at both levels, and a level 1 that is not the last one (its low-pass goes to the scratch plane).
+bool fuse_eligible(const akoHipPlan* pl, const Group& g, bool u8_level0)
+{
+	if (!pl->tune.fuse || !u8_level0 || pl->channels != 4 || g.levels.size() < 3)
+		return false;
+	const LevelGeom &L0 = g.levels[0], &L1 = g.levels[1];
+	if (pl->s.wrap != AKO_WRAP_CLAMP && pl->s.wrap != AKO_WRAP_ZERO)
+		return false;
+	if ((L0.cw % 8) != 0 || (L0.ch % 4) != 0 || L0.kind != L1.kind)
+		return false;
+	if (!stream_eligible(pl, L0, true) || !stream_eligible(pl, L1, false))
+		return false;
+	const uint32_t min_cols = (path_mode(pl) == PATH_STREAM) ? 64 : 256;  // below that a fused strip is mostly halo
+	return L0.tw >= min_cols && L0.th >= 96;
+}
+
+StreamGeom fused_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit)
+{
+	StreamGeom G;
+	G.strips = (L.tw + FNET - 1) / FNET;
+	G.wide = 0;
+	G.lockstep = (uint32_t)pl->tune.lockstep;
+	// the fused walk re-computes 18 row slots per segment: longer segments than the plain level-0 kernel's, two
+	// rounds of 3 waves per SIMD; rows per segment a multiple of 6 (the walk starts on a slot = 3 mod 6), the border
+	// segments 24 rows (the first one and the last one run the spilling border bodies)
+	const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
+	uint64_t segs = (uint64_t)(pl->tune.u8_waves > 0 ? pl->tune.u8_waves : 6144) / per_seg;
+	if (segs < 1)
+		segs = 1;
+	uint32_t seg_rows = (uint32_t)((L.th + segs - 1) / segs);
+	seg_rows = ((seg_rows + 5) / 6) * 6;
+	if (seg_rows < 48)
+		seg_rows = 48;
+	constexpr uint32_t EDGE = 24;
+	G.seg_rows = seg_rows;
+	G.edge_rows = EDGE;
+	G.segs = 3 + (L.th - 3 * EDGE + seg_rows - 1) / seg_rows;
 	return G;
 }
 
@@ -497,15 +553,16 @@ void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, 
 }
 
 template <bool OPT>
-void launch_inverse_u8(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, hipStream_t st)
+void launch_inverse_u8(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st)
 {
-	const dim3 pair(128);  // the workgroup is one pair of waves (LDS plane swap)
+	const dim3 threads(128 * pairs);  // the workgroup is 'pairs' pairs of waves (LDS plane swap inside each pair)
+	const uint32_t lds = pairs * INV_U8_LDS_PER_PAIR;
 	if (kind == K_DD137)
-		hipLaunchKernelGGL((k_inverse_stream_u8<K_DD137, OPT>), dim3(blocks), pair, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_DD137, OPT>), dim3(blocks), threads, lds, st, P, G);
 	else if (kind == K_CDF53)
-		hipLaunchKernelGGL((k_inverse_stream_u8<K_CDF53, OPT>), dim3(blocks), pair, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_CDF53, OPT>), dim3(blocks), threads, lds, st, P, G);
 	else
-		hipLaunchKernelGGL((k_inverse_stream_u8<K_HAAR, OPT>), dim3(blocks), pair, 0, st, P, G);
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_HAAR, OPT>), dim3(blocks), threads, lds, st, P, G);
 }
 
 int check_blocks(uint64_t blocks)
@@ -742,6 +799,50 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			fill_common(P, pl, g, L);
 			P.stream = (int16_t*)d_streams;
 			const bool u8 = (l == 0) && !planes && !staged;
+			if (l == 0 && lt >= 2 && fuse_eligible(pl, g, u8))
+			{
+				// levels 0 and 1 in one strip walk: level 0's low-pass plane is never written
+				const LevelGeom& L1 = g.levels[1];
+				LevelParams P1;
+				fill_common(P1, pl, g, L1);
+				P1.stream = (int16_t*)d_streams;
+				P.img = (uint8_t*)d_images;
+				P.planes_per_wg = 2, P.plane_groups = 2;
+				P1.planes_per_wg = 2, P1.plane_groups = 2;
+				if (nl == 2)
+					P1.ll_out_stream = 1;
+				else
+				{
+					P1.dst = pl->scratch[1];
+					P1.dst_pitch = L1.tw;
+					P1.dst_plane_stride = scratch_plane_elems(g, 1);
+					P1.dst_inst_stride = P1.dst_plane_stride * pl->channels;
+				}
+				const StreamGeom G = fused_geometry(pl, L, (uint64_t)P.plane_groups * insts);
+				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
+				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
+				if (int rc = check_blocks(blocks))
+					return rc;
+				Launch LF{pl, 0};
+				if (int rc = LF.begin())
+					return rc;
+				if (L.kind == K_DD137)
+					hipLaunchKernelGGL((k_forward_fused_u8<K_DD137>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, P1, G);
+				else if (L.kind == K_CDF53)
+					hipLaunchKernelGGL((k_forward_fused_u8<K_CDF53>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, P1, G);
+				else
+					hipLaunchKernelGGL((k_forward_fused_u8<K_HAAR>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, P1, G);
+				char fname[48];
+				snprintf(fname, sizeof fname, "fwd_fused01_%s_u8", kind_name(L.kind));
+				const uint64_t smp0 = (uint64_t)L.cw * L.ch * pl->channels * insts;
+				// algorithmic bytes of the two levels together: pixels in; C / B / D of level 0, everything of level 1 out
+				const uint64_t out0 = ((uint64_t)3 * L.tw * L.th + 1) * pl->channels * insts;
+				const uint64_t out1 = ((uint64_t)4 * L1.tw * L1.th + 1) * pl->channels * insts;
+				if (int rc = LF.end(fname, 0, (uint32_t)gi, smp0, smp0, (out0 + out1) * 2))
+					return rc;
+				l = 1;  // level 1 is done
+				continue;
+			}
 			if (u8)
 			{
 				P.img = (uint8_t*)d_images;
@@ -788,7 +889,8 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
 				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
-				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
+				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.fwd_pairs : (uint32_t)(THREADS / 64);
+				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
 					return rc;
 				// int16 narrowing after every step is a no-op where the worst-case growth of u8-sourced
@@ -799,15 +901,15 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				if (int rc = LA.begin())
 					return rc;
 				if (u8 && (pl->tune.dbg & 16))
-					hipLaunchKernelGGL(k_forward_stream_u8_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+					hipLaunchKernelGGL(k_forward_stream_u8_memonly, dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
 				else if (u8)
 				{
 					if (L.kind == K_DD137)
-						hipLaunchKernelGGL((k_forward_stream_u8<K_DD137>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+						hipLaunchKernelGGL((k_forward_stream_u8<K_DD137>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
 					else if (L.kind == K_CDF53)
-						hipLaunchKernelGGL((k_forward_stream_u8<K_CDF53>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+						hipLaunchKernelGGL((k_forward_stream_u8<K_CDF53>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
 					else
-						hipLaunchKernelGGL((k_forward_stream_u8<K_HAAR>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+						hipLaunchKernelGGL((k_forward_stream_u8<K_HAAR>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
 				}
 				else if (pl->tune.dbg & 16)
 					hipLaunchKernelGGL(k_forward_stream_i16_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
@@ -918,7 +1020,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
 				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
-				const uint32_t waves_per_block = u8 ? 2 : (THREADS / 64);
+				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.inv_pairs : (uint32_t)(THREADS / 64);
 				const int deep = deep_prefetch(pl, G, u8);
 				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
@@ -934,7 +1036,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 					Launch LO{pl, 1};
 					if (int rc = LO.begin())
 						return rc;
-					launch_inverse_u8<true>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_u8<true>(L.kind, P, G, (uint32_t)blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 					snprintf(name, sizeof name, "inv_stream_%s_u8", kind_name(L.kind));
 					const uint64_t smp = (uint64_t)L.cw * L.ch * pl->channels * insts;
 					const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
@@ -944,7 +1046,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_inverse_u8<false>(L.kind, P, G, (uint32_t)blocks, pl->stream);
+					launch_inverse_u8<false>(L.kind, P, G, (uint32_t)blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_inverse_stream<1, false, false, DEEP_SLOTS_SHORT>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep)
@@ -1025,7 +1127,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;

@@ -43,13 +43,13 @@ def hip_decode_body(body, s, ch, w, h):
 
 
 @pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt",
-                        "stream-tail1", "stream-tail2", "stream-nostaged"])
+                        "stream-tail1", "stream-tail2", "stream-nostaged", "auto-fuse", "stream-fuse"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
     kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
     switches the fused in-LDS tail kernel off (AKO_HIP_TAIL=0) so every level runs as its own launch;
     '-noopt' runs the exact int16-wrapping inverse alone instead of optimistic fp32 + exact fallback."""
-    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED")}
+    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE")}
     mode = request.param
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
     # AKO_HIP_TAIL: 0 no fused tail, 1 window-engine tail, 2 segment-engine tail, unset = chosen per launch
@@ -64,6 +64,8 @@ def path_mode(request):
     # '-nostaged': u8 images with 1-3 / 5+ channels keep the window engine on level 0 instead of the
     # u8 -> planar int16 staging in front of the int16 streaming kernels
     os.environ["AKO_HIP_STAGED"] = "0" if mode.endswith("nostaged") else "1"
+    # '-fuse': forward levels 0 and 1 of eligible RGBA plans in one strip walk (k_forward_fused_u8; off by default)
+    os.environ["AKO_HIP_FUSE"] = "1" if mode.endswith("fuse") else "0"
     yield mode
     for k, v in old.items():
         if v is None:
@@ -281,6 +283,50 @@ def test_border_geometries_of_the_streaming_kernels(po, path_mode):
             od, os_, _ = po.decode_image(ob)
             dec = hip_decode_body(ob[16:], os_, ch, w, h)
             assert np.array_equal(dec, od), (w, h, ch, wavelet, wrap, q)
+
+
+def test_fused_levels_0_and_1_forward(po):
+    """AKO_HIP_FUSE=1: forward levels 0 and 1 of an RGBA plan in ONE strip walk (k_forward_fused_u8).
+    Shapes around every way its strips (108 net level-0 coefficient columns each), segments (multiples of 6 rows,
+    18-row lead-in) and borders can fall, all three wavelets, both wraps it takes, tiled and not, colours, gates --
+    byte-for-byte against the oracle, and the kernel records must show that the fused kernel is what ran."""
+    nrng = np.random.default_rng(2718)
+    old = {k: os.environ.get(k) for k in ("AKO_HIP_FUSE", "AKO_HIP_PATH")}
+    cases = [(512, 192, 0), (528, 200, 0), (1024, 1024, 0), (2048, 264, 0), (432, 392, 0), (448, 1000, 0),
+             (1744, 208, 0), (1024, 768, 256), (2048, 1024, 512), (4096, 192, 0), (880, 776, 0)]
+    try:
+        os.environ["AKO_HIP_FUSE"] = "1"
+        for path in ("auto", "stream"):
+            os.environ["AKO_HIP_PATH"] = path
+            for (w, h, tiles) in cases:
+                for wavelet in (0, 1, 2):
+                    wrap = int(nrng.choice([0, 3]))
+                    q = int(nrng.choice([0, 1, 7, 16, 40]))
+                    g = int(nrng.choice([0, 0, 5, 16]))
+                    color = int(nrng.choice([0, 1, 2, 3]))
+                    img = (po.gen_image(0, w, h, int(nrng.integers(1, 1 << 30))) if nrng.random() < 0.5
+                           else nrng.integers(0, 256, (h, w, 4), dtype=np.uint8))
+                    s = po.settings(wavelet=wavelet, wrap=wrap, color=color, compression=2, q=q, g=g, tiles=tiles)
+                    ob, st = po.encode_image(s, img)
+                    assert st == 0
+                    s.color = po.effective_color(s)
+                    with api.Plan(_to_api(s), 4, w, h) as plan:
+                        plan.set_profiling(True)
+                        d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(img)[None]).cuda())
+                        plan.synchronize()
+                        names = [r["name"] for r in plan.kernel_records(False)]
+                        body = d_streams.cpu().numpy().reshape(-1).view(np.uint8)
+                    # 'auto' keeps tiles of fewer than 256 level-0 columns on the separate kernels (a fused strip there
+                    # is mostly halo), 'stream' fuses from 64 columns on; 256-pixel tiles have level 1 in the tail kernel
+                    if (tiles or w) >= 512 or (path == "stream" and tiles == 0):
+                        assert names[0].startswith("fwd_fused01_"), (path, w, h, tiles, wavelet, names[:3])
+                    assert np.array_equal(body, ob[16:]), (path, w, h, tiles, wavelet, wrap, q, g, color)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_optimistic_inverse_around_its_proof_bound(po):
