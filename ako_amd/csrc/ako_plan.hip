@@ -129,6 +129,9 @@ struct Tuning
 	bool opt = true;       // AKO_HIP_OPT=0: exact int16-wrapping inverse alone (no optimistic fp32 launch)
 	bool staged = true;    // AKO_HIP_STAGED=0: no planar staging of 1-3 / 5+ channel u8 images
 	bool deep = true;      // AKO_HIP_DEEP=0: small levels keep the running two-slot prefetch
+	int seg_rows_mid = 0, seg_rows_mid_inv = 0;  // AKO_HIP_SEG_ROWS_MID / _MID_INV: same for int16 levels of 1024..2047
+	                                             // columns, forward / inverse kernels
+	int floor_big = 24;    // AKO_HIP_FLOOR_BIG: fewest rows per segment of levels with >= 2048 columns
 	int u8_waves = 0;      // AKO_HIP_U8_WAVES: waves a u8 level launch aims at (0 = two rounds of resident waves)
 	int lockstep = 3;      // AKO_HIP_LOCKSTEP: StreamGeom::lockstep (bit 0 barrier every six slots, bit 1 strip-major units)
 	int fwd_pairs = 2;     // AKO_HIP_FWD_PAIRS: pairs of waves (= neighbouring strips) per workgroup of the u8 forward kernel
@@ -156,6 +159,11 @@ struct Tuning
 		t.staged = num("AKO_HIP_STAGED", 1) != 0;
 		t.deep = num("AKO_HIP_DEEP", 1) != 0;
 		t.u8_waves = num("AKO_HIP_U8_WAVES", 0);
+		t.floor_big = num("AKO_HIP_FLOOR_BIG", 24);
+		if (t.floor_big < 2)
+			t.floor_big = 2;
+		t.seg_rows_mid = num("AKO_HIP_SEG_ROWS_MID", 0);
+		t.seg_rows_mid_inv = num("AKO_HIP_SEG_ROWS_MID_INV", 0);
 		t.lockstep = num("AKO_HIP_LOCKSTEP", 3) & 3;
 		t.fwd_pairs = num("AKO_HIP_FWD_PAIRS", 2);
 		t.inv_pairs = num("AKO_HIP_INV_PAIRS", 2);
@@ -428,7 +436,7 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 // segments of <= 6 rows + 6 halo slots, or of <= 2 rows
 constexpr int DEEP_SLOTS = 12, DEEP_SLOTS_SHORT = 8;
 
-StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8)
+StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8, bool inverse)
 {
 	StreamGeom G;
 	G.strips = (L.tw + SNET - 1) / SNET;
@@ -441,6 +449,8 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 	uint32_t seg_rows = (uint32_t)pl->tune.seg_rows;
 	if (pl->tune.seg_rows_big != 0 && L.tw >= 1024)  // tuning aid: levels with >= 1024 columns only
 		seg_rows = (uint32_t)pl->tune.seg_rows_big;
+	if (L.tw >= 1024 && L.tw < 2048 && !u8 && seg_rows == 0)  // ... 1024..2047 columns, per direction
+		seg_rows = (uint32_t)(inverse ? pl->tune.seg_rows_mid_inv : pl->tune.seg_rows_mid);
 	if (seg_rows == 0)
 	{
 		// aim at two rounds of resident waves: the u8 kernels run 4 waves per SIMD (8192 waves), the int16
@@ -452,7 +462,10 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
-		const uint32_t floor_rows = (L.tw >= 1024) ? 24 : (pl->tune.seg_rows_small > 0 ? (uint32_t)pl->tune.seg_rows_small : 2);
+		// (level 2 of the 8192 x 8192 image, 1024 columns: 24 -> 12 rows took 42 -> 37 us off each direction)
+		const uint32_t floor_rows = (L.tw >= 2048) ? (uint32_t)pl->tune.floor_big
+		                            : (L.tw >= 1024) ? 12
+		                                             : (pl->tune.seg_rows_small > 0 ? (uint32_t)pl->tune.seg_rows_small : 2);
 		if (seg_rows < floor_rows)
 			seg_rows = floor_rows;
 	}
@@ -601,9 +614,18 @@ size_t tail_start(const akoHipPlan* pl, const Group& g)
 	if (pl->tune.tail_max >= 4 && (uint32_t)pl->tune.tail_max < lim)  // tuning aid: hand smaller levels only to the tail
 		lim = (uint32_t)pl->tune.tail_max;
 	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
+	// A launch with few planes (one workgroup each) leaves most of the chip idle, and the tail's first level is its
+	// most expensive: when that level (65..128 samples) can run as a streaming launch of its own, the tail starts one
+	// level later (8192 x 8192 RGBA, 4 planes: levels >= 6 take 113 -> 91 us for both directions)
+	const uint64_t n_planes = (uint64_t)pl->channels * g.tiles.size() * pl->batch;
 	for (size_t l = planes ? 0 : 1; l < nl; l++)
 		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim)
+		{
+			if (engine == 1 && pl->tune.tail_max == 0 && n_planes <= 32 && l + 1 < nl && l > 0 &&
+			    (g.levels[l].cw > 64 || g.levels[l].ch > 64) && stream_eligible(pl, g.levels[l], false))
+				l++;
 			return (nl - l <= (size_t)TAIL_LEVELS) ? l : nl;
+		}
 	return nl;
 }
 
@@ -887,7 +909,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
-				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8);
+				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8, false);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.fwd_pairs : (uint32_t)(THREADS / 64);
 				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
@@ -1018,7 +1040,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
-				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8);
+				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8, true);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.inv_pairs : (uint32_t)(THREADS / 64);
 				const int deep = deep_prefetch(pl, G, u8);
@@ -1127,7 +1149,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;
