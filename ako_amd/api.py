@@ -14,6 +14,7 @@ calls raise / return the library's error status.
 from __future__ import annotations
 
 import ctypes as C
+import time
 import os
 import weakref
 from typing import Callable, Optional
@@ -262,6 +263,11 @@ def _callbacks(events: Optional[Callable[[int, int, int], None]]):
     return cb, keep
 
 
+# wall-clock of the library call alone inside the most recent encode() / decode() of this module (the wrappers around
+# it copy the blob, and dropping a previous 268 MB result costs more than decoding the next one)
+last_call_seconds = {}
+
+
 def encode(image: np.ndarray, s: Optional[Settings] = None, events=None) -> np.ndarray:
     """akoEncodeExt on an (h, w, channels) or (h, w) uint8 array -> blob (uint8 array)."""
     image = np.ascontiguousarray(image, dtype=np.uint8)
@@ -270,8 +276,10 @@ def encode(image: np.ndarray, s: Optional[Settings] = None, events=None) -> np.n
     cb, keep = _callbacks(events)
     out = C.c_void_p()
     st = C.c_int(-1)
+    t0 = time.perf_counter()
     n = lib().akoEncodeExt(C.byref(cb), C.byref(s) if s is not None else None, ch, w, h,
                            image.ctypes.data_as(C.c_void_p), C.byref(out), C.byref(st))
+    last_call_seconds["akoEncodeExt"] = time.perf_counter() - t0
     del keep
     if n == 0:
         raise AkoError(st.value, "akoEncodeExt", last_error())
@@ -305,8 +313,10 @@ def decode(blob, events=None):
     s = Settings()
     ch, w, h = C.c_size_t(), C.c_size_t(), C.c_size_t()
     st = C.c_int(-1)
+    t0 = time.perf_counter()
     p = lib().akoDecodeExt(C.byref(cb), blob.size, blob.ctypes.data_as(C.c_void_p), C.byref(s), C.byref(ch),
                            C.byref(w), C.byref(h), C.byref(st))
+    last_call_seconds["akoDecodeExt"] = time.perf_counter() - t0
     del keep
     if not p:
         raise AkoError(st.value, "akoDecodeExt", last_error())

@@ -227,6 +227,9 @@ static void* lane_main(void* arg)
 {
 	struct lane* L = arg;
 	struct akoHipBatch* b = L->owner;
+	/* the lanes are the parallelism here: with more than two at work each parses its bit-streams alone */
+	const size_t lanes = b->n_lanes < b->n ? b->n_lanes : b->n;
+	akoHostKagariThreadLimit(lanes > 2 ? 1 : 0);
 	for (;;)
 	{
 		const size_t i = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 /* AKO_HIP_TRACE=1: wall-clock of the stages of the drivers on stderr (where a call's time goes) */
@@ -89,7 +90,11 @@ struct plan_slots
 {
 	akoHipPlan* plans[2];
 	struct plan_key keys[2];
+	/* the decoder's token lists of the previous call, emptied but not freed: for a large image they are tens of
+	 * megabytes whose pages cost more to hand back and fault in again than the parse that fills them */
+	struct akoKagariTokens spare;
 };
+#define SPARE_TOKENS_MAX ((size_t)1 << 30) /* bytes of list capacity worth keeping */
 
 #define POOL_PLANS 8
 #define DOOMED_PLANS 64
@@ -130,6 +135,7 @@ static void slots_park(void* arg)
 		/* (both full: the plan is lost to the process -- 72 parked plans mean nobody is coming back for them) */
 	}
 	pthread_mutex_unlock(&pool_mutex);
+	akoHostKagariTokensFree(&sl->spare);
 	free(sl);
 }
 
@@ -194,6 +200,8 @@ AKO_API void akoHipThreadRelease(void)
 			akoHipPlanDestroy(sl->plans[k]);
 			sl->plans[k] = NULL;
 		}
+	if (sl != NULL)
+		akoHostKagariTokensFree(&sl->spare);
 	akoHipPlan* parked[POOL_PLANS];
 	pthread_mutex_lock(&pool_mutex);
 	for (int e = 0; e < POOL_PLANS; e++)
@@ -256,6 +264,31 @@ static void plan_release(int slot, akoHipPlan* plan, int healthy)
 		akoHipPlanDestroy(plan);
 }
 
+/* the calling thread's spare token lists (empty ones if it has none); taken OUT while in use */
+static void tokens_take(struct akoKagariTokens* tok)
+{
+	memset(tok, 0, sizeof *tok);
+	struct plan_slots* sl = plan_cache_on() ? thread_slots(1) : NULL;
+	if (sl != NULL)
+	{
+		*tok = sl->spare;
+		memset(&sl->spare, 0, sizeof sl->spare);
+		tok->n_literals = 0, tok->n_runs = 0;
+	}
+}
+static void tokens_give(struct akoKagariTokens* tok)
+{
+	struct plan_slots* sl = plan_cache_on() ? thread_slots(0) : NULL;
+	const size_t held = tok->cap_literals * sizeof(int16_t) + tok->cap_runs * sizeof(struct akoKagariRun);
+	if (sl != NULL && sl->spare.literals == NULL && sl->spare.runs == NULL && held <= SPARE_TOKENS_MAX)
+	{
+		sl->spare = *tok;
+		memset(tok, 0, sizeof *tok);
+	}
+	else
+		akoHostKagariTokensFree(tok);
+}
+
 /* ---- tiles of a Kagari blob parsed in parallel -----------------------------------------------
  * A tile's bit-stream can only be walked sequentially, but tiles are independent (library/encode.c:115-205):
  * worker threads pull tile numbers and tokenize them into per-tile lists; the caller then merges the lists
@@ -267,12 +300,15 @@ struct tile_job
 	size_t values, out_base;
 	struct akoKagariTokens tok;
 	size_t used;
+	size_t lit_base, run_base; /* where the tile's tokens go in the image's lists (merge_window) */
+	int merged;
 };
 struct tile_pool
 {
 	struct tile_job* jobs;
 	size_t count;
 	size_t next; /* atomically incremented */
+	struct akoKagariTokens* merge_into; /* NULL: parse; else: move the parsed lists there */
 };
 
 static void* tile_worker(void* arg)
@@ -284,7 +320,23 @@ static void* tile_worker(void* arg)
 		if (t >= pool->count)
 			return NULL;
 		struct tile_job* j = &pool->jobs[t];
-		j->used = (j->payload != NULL) ? akoHostKagariTokenize(j->values, j->block, j->payload, j->out_base, &j->tok) : 0;
+		if (pool->merge_into != NULL)
+		{
+			struct akoKagariTokens* dst = pool->merge_into;
+			if (j->tok.n_literals)
+				memcpy(dst->literals + j->lit_base, j->tok.literals, j->tok.n_literals * sizeof(int16_t));
+			for (size_t k = 0; k < j->tok.n_runs; k++)
+			{
+				struct akoKagariRun r = j->tok.runs[k];
+				r.after += (uint32_t)j->lit_base;
+				dst->runs[j->run_base + k] = r;
+			}
+			akoHostKagariTokensFree(&j->tok);
+			j->merged = 1;
+			continue;
+		}
+		/* one thread per tile here: the tiles are what runs in parallel */
+		j->used = (j->payload != NULL) ? akoHostKagariTokenizeWith(1, j->values, j->block, j->payload, j->out_base, &j->tok) : 0;
 	}
 }
 
@@ -295,9 +347,47 @@ static size_t tokenize_workers(void)
 	return workers > 16 ? 16 : workers;
 }
 
+static void run_tile_pool(struct tile_pool* pool, size_t workers)
+{
+	pthread_t th[16];
+	size_t started = 0;
+	for (size_t k = 1; k < workers; k++) /* the calling thread is worker 0 */
+		if (pthread_create(&th[started], NULL, tile_worker, pool) == 0)
+			started++;
+	tile_worker(pool);
+	for (size_t k = 0; k < started; k++)
+		pthread_join(th[k], NULL);
+}
+
+/* The parsed lists of a window of tiles -> the image's lists, in tile order, by the same worker threads (one sequential
+ * append per tile was a third of the decoder's time for a 8192 x 8192 image in 512-pixel tiles).  Only when every tile of
+ * the window parsed cleanly: otherwise nothing moves and the per-tile loop of akoDecodeExt reports the first broken tile
+ * exactly as before.  'remaining_tiles' sizes the lists for the windows still to come (address space, not memory). */
+static void merge_window(struct tile_job* jobs, size_t count, struct akoKagariTokens* dst, size_t remaining_tiles)
+{
+	size_t lits = 0, runs = 0;
+	for (size_t k = 0; k < count; k++)
+	{
+		if (jobs[k].payload == NULL || jobs[k].used == 0 || jobs[k].used != jobs[k].block)
+			return;
+		jobs[k].lit_base = dst->n_literals + lits, jobs[k].run_base = dst->n_runs + runs;
+		lits += jobs[k].tok.n_literals, runs += jobs[k].tok.n_runs;
+	}
+	if (dst->n_literals + lits > 0xFFFFFFF0ull || lits < ((size_t)1 << 16))
+		return; /* (small windows: the plain appends are faster than threads) */
+	const size_t more = 1 + remaining_tiles / count;
+	if (!akoHostKagariTokensReserve(dst, lits + lits / 8 * more * 9, runs + runs / 8 * more * 9) &&
+	    !akoHostKagariTokensReserve(dst, lits, runs))
+		return;
+	struct tile_pool pool = {jobs, count, 0, dst};
+	size_t workers = tokenize_workers();
+	run_tile_pool(&pool, workers > count ? count : workers);
+	dst->n_literals += lits, dst->n_runs += runs;
+}
+
 static void tokenize_tiles(struct tile_job* jobs, size_t count)
 {
-	struct tile_pool pool = {jobs, count, 0};
+	struct tile_pool pool = {jobs, count, 0, NULL};
 	size_t workers = tokenize_workers();
 	if (workers > count)
 		workers = count;
@@ -307,14 +397,7 @@ static void tokenize_tiles(struct tile_job* jobs, size_t count)
 		payload += jobs[k].block;
 	if (payload < 64 * 1024)
 		workers = 1;
-	pthread_t th[16];
-	size_t started = 0;
-	for (size_t k = 1; k < workers; k++) /* the calling thread is worker 0 */
-		if (pthread_create(&th[started], NULL, tile_worker, &pool) == 0)
-			started++;
-	tile_worker(&pool);
-	for (size_t k = 0; k < started; k++)
-		pthread_join(th[k], NULL);
+	run_tile_pool(&pool, workers);
 }
 
 /* ---- first touch of a large result buffer, off the critical path ---------------------------------------------
@@ -323,7 +406,7 @@ static void tokenize_tiles(struct tile_job* jobs, size_t count)
  * copying thread).  The pages are touched here instead, by a few helper threads, while the caller's thread is still
  * busy parsing the entropy-coded input; the buffer is the library's own until it is returned, so writing zeros
  * into it is invisible. */
-#define TOUCH_THREADS 4
+#define TOUCH_THREADS 16
 struct toucher
 {
 	uint8_t* base;
@@ -343,8 +426,24 @@ static void touch_begin(struct toucher* ts, uint8_t* base, size_t bytes)
 	memset(ts, 0, TOUCH_THREADS * sizeof *ts);
 	if (bytes < ((size_t)16 << 20))
 		return;
-	const size_t part = ((bytes / TOUCH_THREADS) + 4095) & ~(size_t)4095;
-	for (size_t k = 0; k < TOUCH_THREADS; k++)
+	/* AKO_HIP_TOUCH_THREADS: helper threads (default 4, 0 = none, 16 at most) */
+	size_t threads = 4;
+	const char* e = getenv("AKO_HIP_TOUCH_THREADS");
+	if (e != NULL && e[0] != 0)
+		threads = (size_t)atol(e);
+	if (threads > TOUCH_THREADS)
+		threads = TOUCH_THREADS;
+	if (threads == 0)
+		return;
+	/* huge pages where the system hands them out on request: 128 faults instead of 65536 for a 268 MB image */
+	{
+		const uintptr_t lo = ((uintptr_t)base + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+		const uintptr_t hi = ((uintptr_t)base + bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+		if (hi > lo)
+			(void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+	}
+	const size_t part = ((bytes / threads) + 4095) & ~(size_t)4095;
+	for (size_t k = 0; k < threads; k++)
 	{
 		const size_t lo = k * part;
 		if (lo >= bytes)
@@ -785,6 +884,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	size_t n_jobs = 0;
 	struct toucher touchers[TOUCH_THREADS];
 	memset(touchers, 0, sizeof touchers);
+	double t_call = tracing() ? now_ms() : 0.0;
 
 	const struct akoCallbacks cb = (c != NULL) ? *c : akoDefaultCallbacks();
 	if (cb.malloc == NULL || cb.realloc == NULL || cb.free == NULL)
@@ -942,14 +1042,15 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 	if (st.compression != AKO_COMPRESSION_NONE && !(kg_env != NULL && strcmp(kg_env, "host") == 0) &&
 	    stream_bytes / 2 <= 0xFFFFFFF0ull)
 	{
-		double t_trace = tracing() ? now_ms() : 0.0;
+		double t_trace = t_call;
+		TRACE("decode: head, plan", t_trace);
 		if ((image = cb.malloc(image_w * image_h * channels)) == NULL)
 		{
 			status = AKO_NO_ENOUGH_MEMORY;
 			goto failure;
 		}
 		touch_begin(touchers, image, image_w * image_h * channels);
-		memset(&tokens, 0, sizeof tokens);
+		tokens_take(&tokens);
 
 		/* several tiles: they are parsed on worker threads, a bounded WINDOW of tiles at a time (host memory stays
 		 * proportional to the window, not to the tile count: an 8192x8192 image in 8 pixel tiles has a million),
@@ -1013,6 +1114,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 					walk += (size_t)blk + 4;
 				}
 				tokenize_tiles(jobs, win_count);
+				merge_window(jobs, win_count, &tokens, tiles - t - win_count);
 			}
 			if (jobs != NULL)
 			{
@@ -1023,14 +1125,17 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 					status = AKO_BROKEN_INPUT;
 					goto failure;
 				}
-				const size_t base = tokens.n_literals;
-				if (base + j->tok.n_literals > 0xFFFFFFF0ull ||
-				    !akoHostKagariTokensAppend(&tokens, &j->tok, (uint32_t)base))
+				if (!j->merged)
 				{
-					status = AKO_NO_ENOUGH_MEMORY;
-					goto failure;
+					const size_t base = tokens.n_literals;
+					if (base + j->tok.n_literals > 0xFFFFFFF0ull ||
+					    !akoHostKagariTokensAppend(&tokens, &j->tok, (uint32_t)base))
+					{
+						status = AKO_NO_ENOUGH_MEMORY;
+						goto failure;
+					}
+					akoHostKagariTokensFree(&j->tok);
 				}
-				akoHostKagariTokensFree(&j->tok);
 			}
 			else
 			{
@@ -1076,9 +1181,10 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 			fire(&cb, t, tiles, AKO_EVENT_FORMAT_START);
 			fire(&cb, t, tiles, AKO_EVENT_FORMAT_END);
 		}
-		akoHostKagariTokensFree(&tokens);
+		tokens_give(&tokens);
 		free(jobs); /* every per-tile list was released when it was merged */
 		jobs = NULL;
+		TRACE("decode: release token lists", t_trace);
 		goto decoded;
 	}
 
@@ -1153,6 +1259,7 @@ decoded:
 	plan_release(1, plan, 1);
 	if (streams != NULL)
 		cb.free(streams);
+	TRACE("decode: the whole call", t_call);
 
 	if (out_s != NULL)
 		*out_s = st;

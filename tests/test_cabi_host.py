@@ -308,6 +308,116 @@ def test_kagari_tokenizer_equals_decoder():
         L.akoHostKagariTokensFree(C.byref(tok))
 
 
+def _tokens_snapshot(tok):
+    lit = np.ctypeslib.as_array(tok.literals, shape=(tok.n_literals,)).copy() if tok.n_literals else np.zeros(0, np.int16)
+    runs = [(tok.runs[k].out_start, tok.runs[k].count, tok.runs[k].after) for k in range(tok.n_runs)]
+    return lit, runs
+
+
+def test_kagari_tokenizer_in_parallel_equals_the_sequential_parse(po):
+    """Blocks of >= 128 KiB are parsed by several threads that start speculatively inside the bit-stream and join
+    where they re-synchronise (ako_kagari.c).  With the threshold lowered so that small blocks take that route:
+    same token lists, same return value as the sequential loop -- for clean blocks of every flavour (where the
+    threads must actually have done the work), for blocks appended to existing lists at an offset, and for damaged,
+    truncated, padded and mis-sized blocks (which the threads hand back to the sequential loop)."""
+    L = api.lib()
+    V = C.c_void_p
+    L.akoHostKagariParallelStats.restype = None
+    acc, back = C.c_size_t(0), C.c_size_t(0)
+
+    def stats():
+        L.akoHostKagariParallelStats(C.byref(acc), C.byref(back))
+        return acc.value, back.value
+
+    def tokenize(values, length, buf, base, threads, prefix=None):
+        os.environ["AKO_KAGARI_THREADS"] = str(threads)
+        tok = api.KagariTokens()
+        if prefix is not None:  # lists that already hold another block's tokens
+            pv = np.ascontiguousarray(prefix.astype(np.int16))
+            pk = np.zeros(8 * pv.size + 64, dtype=np.uint8)
+            ps = L.akoHostKagariEncode(pv.size * 2, pk.size, pv.ctypes.data_as(V), pk.ctypes.data_as(V))
+            os.environ["AKO_KAGARI_THREADS"] = "1"
+            assert L.akoHostKagariTokenize(pv.size, ps, pk.ctypes.data_as(V), 0, C.byref(tok)) == ps
+            os.environ["AKO_KAGARI_THREADS"] = str(threads)
+        used = L.akoHostKagariTokenize(values, length, buf.ctypes.data_as(V), base, C.byref(tok))
+        snap = _tokens_snapshot(tok)
+        L.akoHostKagariTokensFree(C.byref(tok))
+        return used, snap
+
+    old = {k: os.environ.get(k) for k in ("AKO_KAGARI_THREADS", "AKO_KAGARI_PAR_MIN")}
+    rng = np.random.default_rng(77)
+    try:
+        os.environ["AKO_KAGARI_PAR_MIN"] = "256"
+        clean_parallel = 0
+        for trial in range(60):
+            n = int(rng.integers(2000, 120000))
+            kind = trial % 6
+            if kind == 0:
+                v = rng.integers(-3, 4, n)
+            elif kind == 1:
+                v = np.repeat(rng.integers(-9, 9, (n + 15) // 16), 16)[:n]
+            elif kind == 2:
+                v = np.where(rng.random(n) < 0.93, 0, rng.integers(-5000, 5000, n))
+            elif kind == 3:
+                v = rng.integers(-32767, 32768, n)           # long codes, no runs (-32768 has no code)
+            elif kind == 4:
+                v = np.zeros(n)                              # a handful of maximal runs: most ranges hold no code start
+                v[rng.integers(0, n, 5)] = 9
+            else:                                            # a real coefficient stream
+                s = po.settings(wavelet=0, compression=2, q=int(rng.integers(0, 30)), g=int(rng.integers(0, 20)))
+                ob, st = po.encode_image(s, po.gen_image(0, 160, 120, int(rng.integers(1, 1 << 30))))
+                assert st == 0
+                v = ob[16:].view(np.int16)
+                n = v.size
+            v = np.ascontiguousarray(np.asarray(v).astype(np.int16))
+            packed = np.zeros(8 * n + 64, dtype=np.uint8)
+            size = L.akoHostKagariEncode(n * 2, packed.size, v.ctypes.data_as(V), packed.ctypes.data_as(V))
+            assert size > 0
+            base = int(rng.integers(0, 1 << 20))
+            prefix = rng.integers(-2, 3, int(rng.integers(1, 500))) if trial % 2 else None
+            ref = tokenize(n, size, packed, base, 1, prefix)
+            assert ref[0] == size
+            for threads in (2, 3, 8, 16):
+                before = stats()
+                got = tokenize(n, size, packed, base, threads, prefix)
+                after = stats()
+                assert got[0] == ref[0], (trial, threads)
+                assert np.array_equal(got[1][0], ref[1][0]) and got[1][1] == ref[1][1], (trial, threads)
+                if size >= 256:
+                    assert (after[0] - before[0]) + (after[1] - before[1]) == 1, (trial, threads, size)
+                    clean_parallel += after[0] - before[0]
+            # damaged / mis-sized blocks: the sequential verdict, whatever the threads made of them
+            for damage in range(8):
+                bad, length, values = packed[:size].copy(), size, n
+                if damage < 3:
+                    bad[int(rng.integers(0, size))] ^= 1 << int(rng.integers(0, 8))
+                elif damage == 3:
+                    length = int(rng.integers(1, size + 1))
+                elif damage == 4:
+                    bad = np.concatenate([bad, rng.integers(0, 256, 5, dtype=np.uint8)])
+                    length = bad.size
+                elif damage == 5:
+                    bad = np.concatenate([bad, np.zeros(3, dtype=np.uint8)])  # zero padding behind the last code
+                    length = bad.size
+                elif damage == 6:
+                    values = n + 1
+                else:
+                    values = n - 1
+                bad = np.ascontiguousarray(bad)
+                want = tokenize(values, length, bad, base, 1)
+                got = tokenize(values, length, bad, base, 8)
+                assert got[0] == want[0], (trial, damage, got[0], want[0])
+                if want[0]:
+                    assert np.array_equal(got[1][0], want[1][0]) and got[1][1] == want[1][1], (trial, damage)
+        assert clean_parallel > 150, clean_parallel  # the threads finished most clean blocks themselves
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
 def test_kagari_decoder_verdicts_on_damaged_payloads_match_the_oracle(po):
     """compression.c:69 accepts a block only when the decoder reports exactly the block size as consumed, and
     kagari.c reports the bytes its eager reader FETCHED: on damaged payloads the verdict depends on that fetch
