@@ -198,6 +198,9 @@ def lib() -> C.CDLL:
     L.akoHipRequantize.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.akoHipHostAlloc.restype = vp
     L.akoHipHostAlloc.argtypes = [sz]
+    if hasattr(L, "akoHipHostIsPinned"):
+        L.akoHipHostIsPinned.restype = C.c_int
+        L.akoHipHostIsPinned.argtypes = [vp]
     L.akoHipHostFree.restype = None
     L.akoHipHostFree.argtypes = [vp]
     L.akoHostSynthImage.restype = None
@@ -326,6 +329,19 @@ def decode(blob, events=None):
     img = np.frombuffer((C.c_uint8 * n).from_address(p), dtype=np.uint8).reshape(h.value, w.value, ch.value).view(_Owned)
     img._release = weakref.finalize(img, lib().akoDefaultFree, C.c_void_p(p))
     return img, s
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """An uninitialised array in page-locked host memory (akoHipHostAlloc): device copies to / from it run at link
+    rate, and the batched API uses it in place.  Freed (akoHipHostFree) when the array and its views are gone."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = lib().akoHipHostAlloc(max(n, 1))
+    if not p:
+        raise MemoryError(f"akoHipHostAlloc({n})")
+    a = np.frombuffer((C.c_uint8 * n).from_address(p), dtype=dt).reshape(shape).view(_Owned)
+    a._release = weakref.finalize(a, lib().akoHipHostFree, C.c_void_p(p))
+    return a
 
 
 class _Owned(np.ndarray):
@@ -537,14 +553,19 @@ class Batch:
                 blobs.append(None)
         return blobs, list(st)
 
-    def decode(self, blobs):
-        """blobs of images of this batch's shape -> (list of (h, w, channels) arrays | None, list of status)."""
+    def decode(self, blobs, outs=None):
+        """blobs of images of this batch's shape -> (list of (h, w, channels) arrays | None, list of status).
+        outs: arrays to decode into (reused buffers, or pinned ones from pinned_empty(): those are filled by the
+        device copy itself)."""
         bl = [np.ascontiguousarray(np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else b, dtype=np.uint8)
               for b in blobs]
         n = len(bl)
         ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bl])
         sizes = (C.c_size_t * n)(*[b.size for b in bl])
-        outs = [np.empty((self.h, self.w, self.channels), dtype=np.uint8) for _ in range(n)]
+        if outs is None:
+            outs = [np.empty((self.h, self.w, self.channels), dtype=np.uint8) for _ in range(n)]
+        assert len(outs) == n and all(o.dtype == np.uint8 and o.flags.c_contiguous and o.size == self.h * self.w * self.channels
+                                      for o in outs)
         optr = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         st = (C.c_int * n)()
         lib().akoHipDecodeBatch(self._b, n, ptrs, sizes, optr, st)

@@ -1453,6 +1453,17 @@ void akoHipHostFree(void* p)
 		(void)hipHostFree(p);
 }
 
+int akoHipHostIsPinned(const void* p)
+{
+	hipPointerAttribute_t attr;
+	if (p == nullptr || hipPointerGetAttributes(&attr, p) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return 0;
+	}
+	return attr.type == hipMemoryTypeHost;
+}
+
 int akoHipSynchronize(akoHipPlan* pl)
 {
 	HIP_TRY(hipSetDevice(pl->device));

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 struct lane
 {
@@ -169,10 +170,15 @@ static enum akoStatus encode_one(struct lane* L, size_t i)
 	    (L->enc_plan = akoHipPlanCreate(L->device, &b->s, b->channels, b->w, b->h, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &st)) == NULL)
 		return st;
 
-	memcpy(L->pin_in, b->in[i], b->image_bytes); /* the only pass of the host over the pixels */
+	const void* pixels = b->in[i];
+	if (!akoHipHostIsPinned(pixels))
+	{
+		memcpy(L->pin_in, pixels, b->image_bytes); /* the only pass of the host over the pixels */
+		pixels = L->pin_in;
+	}
 	uint8_t* blob = NULL;
 	size_t body = 0;
-	if ((st = akoHostEncodeBody(L->enc_plan, b->s.compression, L->pin_in, sizeof(struct akoHead), &blob, &body)) != AKO_OK)
+	if ((st = akoHostEncodeBody(L->enc_plan, b->s.compression, pixels, sizeof(struct akoHead), &blob, &body)) != AKO_OK)
 		return st;
 	if ((st = akoHostHeadWrite(b->channels, b->w, b->h, &b->s, blob)) != AKO_OK)
 	{
@@ -214,10 +220,21 @@ static enum akoStatus decode_one(struct lane* L, size_t i)
 			return st;
 		L->dec_settings = hs;
 	}
+	const int direct = akoHipHostIsPinned(b->out[i]);
 	if ((st = akoHostDecodeBody(L->dec_plan, hs.compression, blob + sizeof(struct akoHead), size - sizeof(struct akoHead), NULL,
-	                            L->pin_out)) != AKO_OK)
+	                            direct ? b->out[i] : (void*)L->pin_out)) != AKO_OK)
 		return st;
-	memcpy(b->out[i], L->pin_out, b->image_bytes);
+	if (!direct)
+	{
+		if (b->image_bytes >= ((size_t)4 << 20)) /* a fresh buffer: 2 MB faults instead of 4 KB ones where the system allows */
+		{
+			const uintptr_t lo = ((uintptr_t)b->out[i] + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+			const uintptr_t hi = ((uintptr_t)b->out[i] + b->image_bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+			if (hi > lo)
+				(void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+		}
+		memcpy(b->out[i], L->pin_out, b->image_bytes);
+	}
 	if (b->out_sizes != NULL)
 		b->out_sizes[i] = b->image_bytes;
 	return AKO_OK;
@@ -266,7 +283,8 @@ AKO_API akoHipBatch* akoHipBatchCreate(const int* devices, size_t n_devices, siz
 	if (devices == NULL || n_devices == 0)
 		devices = &dev0, n_devices = 1;
 	if (lanes_per_device == 0)
-		lanes_per_device = 6; /* 3840x2160 RGBA on one MI355X: 2 lanes 6.7, 4 lanes 9.1, 6 lanes 12.2 Gpx/s (link bound 13.8) */
+		lanes_per_device = 8; /* 3840x2160 RGBA on one MI355X, encode / decode Gpx/s (link bound 13.8): 4 lanes 7.7 / 5.5,
+		                       * 6 lanes 10.2-11.6 / 7.2-7.6, 8 lanes 10.3-11.0 / 10.2-10.5, 12 lanes 10.8-12.6 / 9.5-11.8 */
 	if (settings == NULL || channels == 0 || image_w == 0 || image_h == 0 || n_devices > 64 || lanes_per_device > 16)
 	{
 		st = AKO_INVALID_INPUT;

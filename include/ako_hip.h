@@ -189,11 +189,13 @@ void akoHipThreadRelease(void);
  * byte-identical to akoEncodeExt's for the same image and settings.
  *
  * akoHipBatchCreate   devices: n_devices HIP device indices (NULL: device 0; a device may appear more than once);
- *                     lanes_per_device 0 = default (6)
+ *                     lanes_per_device 0 = default (8)
  * akoHipEncodeBatch   images[i]: image_w * image_h * channels bytes each.  out_blobs[i] / out_sizes[i]: a malloc'ed
  *                     blob per image (release with akoDefaultFree), NULL / 0 where out_status[i] != AKO_OK
  *                     (out_status may be NULL).  Returns 0 when every image was encoded
- * akoHipDecodeBatch   blobs of images of the batch's shape -> images[i] (caller's buffers of image bytes each) */
+ * akoHipDecodeBatch   blobs of images of the batch's shape -> images[i] (caller's buffers of image bytes each)
+ * Images in pinned memory (akoHipHostAlloc) are copied to / from the device directly; pageable ones go through the
+ * lane's pinned staging (one pass of a lane thread over the pixels). */
 typedef struct akoHipBatch akoHipBatch;
 akoHipBatch* akoHipBatchCreate(const int* devices, size_t n_devices, size_t lanes_per_device,
                                const struct akoSettings* settings, size_t channels, size_t image_w, size_t image_h,
@@ -208,6 +210,7 @@ int akoHipDecodeBatch(akoHipBatch*, size_t n_blobs, const void* const* blobs, co
 /* pinned host memory (hipHostMalloc): page-locked, so copies to / from the device run at link rate and asynchronously */
 void* akoHipHostAlloc(size_t bytes);
 void akoHipHostFree(void* p);
+int akoHipHostIsPinned(const void* p); /* 1: page-locked memory the HIP runtime knows (akoHipHostAlloc, hipHostRegister) */
 
 #ifdef __cplusplus
 }

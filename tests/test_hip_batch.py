@@ -36,6 +36,36 @@ def test_encode_batch_equals_per_image_encode_and_the_oracle(po):
                 assert np.array_equal(decs[i], want), (comp, q, td, i)
 
 
+def test_batch_with_pinned_and_reused_buffers(po):
+    """Images in page-locked memory (akoHipHostAlloc) are used in place by the lanes, pageable ones go through the
+    lanes' staging: same blobs, same pixels either way, also when the output buffers of an earlier call are handed
+    in again; mixed lists work."""
+    w, h, n = 1024, 544, 12          # 2.2 MB images: the decode path also takes its huge-page advice branch
+    imgs = [po.gen_image(0, w, h, seed=77 + i) for i in range(n)]
+    s = api.settings(wavelet=api.DD137, compression=api.KAGARI, q=9, g=4)
+    assert api.lib().akoHipHostIsPinned(imgs[0].ctypes.data) == 0
+    with api.Batch(s, 4, w, h, devices=[0], lanes_per_device=3) as b:
+        blobs, st = b.encode(imgs)
+        assert st == [0] * n
+        pin_in = [api.pinned_empty((h, w, 4)) for _ in range(n)]
+        assert api.lib().akoHipHostIsPinned(pin_in[0].ctypes.data) == 1
+        for a, im in zip(pin_in, imgs):
+            a[...] = im
+        mixed = [pin_in[i] if i % 2 else imgs[i] for i in range(n)]
+        blobs_p, st = b.encode(mixed)
+        assert st == [0] * n and all(np.array_equal(x, y) for x, y in zip(blobs_p, blobs))
+        want = [po.decode_image(bl)[0] for bl in blobs]
+        decs, st = b.decode(blobs)
+        assert st == [0] * n and all(np.array_equal(x, y) for x, y in zip(decs, want))
+        for d in decs:
+            d[...] = 0
+        again, st = b.decode(blobs, outs=decs)                       # the same pageable buffers
+        assert st == [0] * n and all(x is y for x, y in zip(again, decs)) and all(np.array_equal(x, y) for x, y in zip(again, want))
+        outs = [api.pinned_empty((h, w, 4)) if i % 2 else np.zeros((h, w, 4), np.uint8) for i in range(n)]
+        got, st = b.decode(blobs, outs=outs)                         # pinned and pageable, mixed
+        assert st == [0] * n and all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
 def test_batch_reports_per_image_failures(po):
     import ctypes as C
 
