@@ -99,6 +99,7 @@ struct LevelParams
 	float rq_luma, rq_chroma;  // (1/q) * (1 + 1e-6): see quantize()
 	uint32_t dbg;              // AKO_HIP_DBG: bit 2 switches the XCD-aware workgroup order of the streaming kernels off
 	int32_t* ovf_flag;         // optimistic-float inverse: set when a value may have left int16 (see ako_stream.hip.h)
+	int32_t ovf_gen;           // ... to this launch's generation number (> every earlier one: the flag is never reset)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -194,6 +194,7 @@ struct akoHipPlan
 	void* d_img = nullptr;
 	void* d_stream = nullptr;
 	int32_t* d_flags = nullptr;  // overflow flags of the optimistic inverse launches
+	int32_t ovf_gen = 0;         // generation number of the latest one
 	int16_t* planes0 = nullptr;  // planar int16 image: staging for u8 images with 1-3 or 5+ channels (staged_level0)
 	// profiling
 	bool profiling = false;
@@ -1053,8 +1054,15 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				if (optimistic)
 				{
 					const size_t slot = (gi * 8 + l) % 64;
-					HIP_TRY(hipMemsetAsync(pl->d_flags + slot, 0, sizeof(int32_t), pl->stream));
+					// the flag is never reset: an optimistic launch raises it to its generation number (they only
+					// grow), the exact kernel behind it works only if it finds exactly that number
+					if (pl->ovf_gen == INT32_MAX)
+					{
+						HIP_TRY(hipMemsetAsync(pl->d_flags, 0, 64 * sizeof(int32_t), pl->stream));
+						pl->ovf_gen = 0;
+					}
 					P.ovf_flag = pl->d_flags + slot;
+					P.ovf_gen = ++pl->ovf_gen;
 					Launch LO{pl, 1};
 					if (int rc = LO.begin())
 						return rc;
@@ -1285,6 +1293,8 @@ akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, siz
 		// everything a first call would otherwise allocate inside its (possibly timed) launch sequence
 		if (hipMalloc((void**)&pl->d_flags, 64 * sizeof(int32_t)) != hipSuccess)
 			PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(overflow flags) failed");
+		if (hipMemset(pl->d_flags, 0, 64 * sizeof(int32_t)) != hipSuccess)
+			PLAN_FAIL(AKO_ERROR, "hipMemset(overflow flags) failed");
 		for (const Group& g : pl->groups)
 			if (pl->planes0 == nullptr && staged_level0(pl, g) && tail_start(pl, g) > 0 && ensure_planes0(pl) != 0)
 				PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(planar staging image) failed");

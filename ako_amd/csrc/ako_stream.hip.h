@@ -1970,7 +1970,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	{
 		const bool bad = !(peak_in <= OPT_INPUT_BOUND) || !(peak_out <= OPT_OUTPUT_BOUND);  // negated: NaN counts as bad
 		if (__any(bad) && lane == 0)
-			atomicOr(P.ovf_flag, 1);
+			atomicMax(P.ovf_flag, P.ovf_gen);
 	}
 }
 
@@ -1981,7 +1981,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	if (!OPT && P.ovf_flag != nullptr)
 	{
 		// exact re-run behind an optimistic launch: nothing to do unless that launch raised the flag
-		if (__builtin_amdgcn_readfirstlane(*(volatile const int32_t*)P.ovf_flag) == 0)
+		if (__builtin_amdgcn_readfirstlane(*(volatile const int32_t*)P.ovf_flag) != P.ovf_gen)
 			return;
 	}
 	const UnitId id = decode_unit(P, G);
@@ -2018,7 +2018,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	uint4(*xbuf)[2][2][64] = reinterpret_cast<uint4(*)[2][2][64]>(xdyn + (threadIdx.x >> 7) * (2 * 2 * 2 * 64));
 	if (!OPT && P.ovf_flag != nullptr)
 	{
-		if (__builtin_amdgcn_readfirstlane(*(volatile const int32_t*)P.ovf_flag) == 0)
+		if (__builtin_amdgcn_readfirstlane(*(volatile const int32_t*)P.ovf_flag) != P.ovf_gen)
 			return;
 	}
 	const UnitId id = decode_unit(P, G);
