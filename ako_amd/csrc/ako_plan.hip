@@ -679,7 +679,17 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 		return rc;
 	const bool seg_engine = tail_engine(pl, g) == 2;
 	T.pitch = 2 * g.levels[lt].tw;
-	size_t lds_bytes = TAIL_LDS_BYTES;
+	// window engine: LDS and threads by the size of the first (largest) level -- a tiled image has thousands of tiny
+	// planes here (16384 x 16384 in 256-pixel tiles: 16384 planes of 8 x 8), and at the full 48 KB / 1024 threads only
+	// three of them fit a CU at a time
+	const LevelGeom& L0t = g.levels[lt];
+	T.win_elems = 2 * (L0t.th + 6) * 2 * (L0t.tw + 8);
+	size_t lds_bytes = ((size_t)T.win_elems + (size_t)L0t.tw * L0t.th) * sizeof(int16_t);
+	if (!seg_engine && lds_bytes > (size_t)TAIL_LDS_BYTES)
+		return fail(AKO_ERROR, "tail level larger than the tail kernel's window%s%s");
+	uint32_t tail_threads = 64;
+	while (tail_threads < (uint32_t)TAIL_THREADS && (uint64_t)tail_threads * 4 < (uint64_t)L0t.cw * L0t.ch)
+		tail_threads *= 2;
 	if (seg_engine)
 	{
 		lds_bytes = (size_t)(2 * g.levels[lt].th) * T.pitch * sizeof(int16_t);
@@ -705,9 +715,9 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 	else
 	{
 		if (decode)
-			hipLaunchKernelGGL(k_inverse_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), lds_bytes, pl->stream, T);
+			hipLaunchKernelGGL(k_inverse_tail, dim3((uint32_t)blocks), dim3(tail_threads), lds_bytes, pl->stream, T);
 		else
-			hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(TAIL_THREADS), lds_bytes, pl->stream, T);
+			hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(tail_threads), lds_bytes, pl->stream, T);
 	}
 	const uint64_t units = samples * blocks;
 	return LA.end(decode ? (seg_engine ? "inv_tail_seg" : "inv_tail") : (seg_engine ? "fwd_tail_seg" : "fwd_tail"),

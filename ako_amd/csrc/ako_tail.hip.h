@@ -50,6 +50,7 @@ struct TailParams
 	const TileDesc* tiles;
 	uint32_t n_tiles, batch;
 	uint32_t pitch;           // segment engine: LDS row pitch (elements) = 2 * ceil(lv[0].cw / 2)
+	uint32_t win_elems;       // window engine: elements of the first (largest) level's window; the dense LL array follows
 	// int16 plane side: the LL plane handed over by / to the level kernels (or PLANES_I16 images).
 	// The u8 side (colour transform across planes) never runs here: level 0 of a u8 image is always
 	// a level kernel.
@@ -76,14 +77,14 @@ struct FastDiv
 // The four lifting phases of one level on a window that covers the whole plane (origin slot
 // -ORG_R / -ORG_C, Tc x Tr sub-band coefficients, element pitch wp).
 template <int KIND, int SGN>
-__device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, int Tr, int wrap, int tid)
+__device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, int Tr, int wrap, int tid, int nthreads)
 {
 	const int nrows = 2 * (Tr + 2 * ORG_R);
 	const FastDiv dA(Tc + 3), dB(Tc), dC(2 * Tc), dD(2 * (Tc + 2 * ORG_C));
 	if (SGN > 0)
 	{
 		// rows: predict over slots [-2, Tc], every window row; then update over [0, Tc)
-		for (int idx = tid; idx < nrows * (Tc + 3); idx += TAIL_THREADS)
+		for (int idx = tid; idx < nrows * (Tc + 3); idx += nthreads)
 		{
 			const int wr = dA.div(idx), jj = idx - wr * (Tc + 3);
 			lift_step<KIND, true, +1, true>(W + wr * wp, 1, jj + 2, jj - 2, -ORG_C, Tc, wrap);
@@ -91,7 +92,7 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		__syncthreads();
 		if (KIND != K_HAAR)
 		{
-			for (int idx = tid; idx < nrows * Tc; idx += TAIL_THREADS)
+			for (int idx = tid; idx < nrows * Tc; idx += nthreads)
 			{
 				const int wr = dB.div(idx), jj = idx - wr * Tc;
 				lift_step<KIND, false, +1, false>(W + wr * wp, 1, jj + ORG_C, jj, -ORG_C, Tc, wrap);
@@ -99,7 +100,7 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 			__syncthreads();
 		}
 		// columns: predict over row slots [-2, Tr], the 2*Tc net columns; then update over [0, Tr)
-		for (int idx = tid; idx < (Tr + 3) * (2 * Tc); idx += TAIL_THREADS)
+		for (int idx = tid; idx < (Tr + 3) * (2 * Tc); idx += nthreads)
 		{
 			const int ii = dC.div(idx), x = idx - ii * (2 * Tc);
 			lift_step<KIND, true, +1, true>(W + 2 * ORG_C + x, wp, ii + 1, ii - 2, -ORG_R, Tr, wrap);
@@ -107,7 +108,7 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		__syncthreads();
 		if (KIND != K_HAAR)
 		{
-			for (int idx = tid; idx < Tr * (2 * Tc); idx += TAIL_THREADS)
+			for (int idx = tid; idx < Tr * (2 * Tc); idx += nthreads)
 			{
 				const int ii = dC.div(idx), x = idx - ii * (2 * Tc);
 				lift_step<KIND, false, +1, false>(W + 2 * ORG_C + x, wp, ii + ORG_R, ii, -ORG_R, Tr, wrap);
@@ -121,14 +122,14 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		// columns: evens over row slots [-1, Tr+1], every window column; then odds over [0, Tr)
 		if (KIND != K_HAAR)
 		{
-			for (int idx = tid; idx < (Tr + 3) * ncols; idx += TAIL_THREADS)
+			for (int idx = tid; idx < (Tr + 3) * ncols; idx += nthreads)
 			{
 				const int ii = dD.div(idx), x = idx - ii * ncols;
 				lift_step<KIND, false, -1, true>(W + x, wp, ii + 2, ii - 1, -ORG_R, Tr, wrap);
 			}
 			__syncthreads();
 		}
-		for (int idx = tid; idx < Tr * ncols; idx += TAIL_THREADS)
+		for (int idx = tid; idx < Tr * ncols; idx += nthreads)
 		{
 			const int ii = dD.div(idx), x = idx - ii * ncols;
 			lift_step<KIND, true, -1, false>(W + x, wp, ii + ORG_R, ii, -ORG_R, Tr, wrap);
@@ -137,14 +138,14 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 		// rows: evens over slots [-1, Tc+1], the 2*Tr net rows; then odds over [0, Tc)
 		if (KIND != K_HAAR)
 		{
-			for (int idx = tid; idx < (2 * Tr) * (Tc + 3); idx += TAIL_THREADS)
+			for (int idx = tid; idx < (2 * Tr) * (Tc + 3); idx += nthreads)
 			{
 				const int y = dA.div(idx), jj = idx - y * (Tc + 3);
 				lift_step<KIND, false, -1, true>(W + (2 * ORG_R + y) * wp, 1, jj + 3, jj - 1, -ORG_C, Tc, wrap);
 			}
 			__syncthreads();
 		}
-		for (int idx = tid; idx < (2 * Tr) * Tc; idx += TAIL_THREADS)
+		for (int idx = tid; idx < (2 * Tr) * Tc; idx += nthreads)
 		{
 			const int y = dB.div(idx), jj = idx - y * Tc;
 			lift_step<KIND, true, -1, false>(W + (2 * ORG_R + y) * wp, 1, jj + ORG_C, jj, -ORG_C, Tc, wrap);
@@ -154,22 +155,22 @@ __device__ __forceinline__ void tail_level_passes(int16_t* W, int wp, int Tc, in
 }
 
 template <int SGN>
-__device__ __forceinline__ void tail_level_dispatch(int kind, int16_t* W, int wp, int Tc, int Tr, int wrap, int tid)
+__device__ __forceinline__ void tail_level_dispatch(int kind, int16_t* W, int wp, int Tc, int Tr, int wrap, int tid, int nthreads)
 {
 	if (kind == K_DD137)
-		tail_level_passes<K_DD137, SGN>(W, wp, Tc, Tr, wrap, tid);
+		tail_level_passes<K_DD137, SGN>(W, wp, Tc, Tr, wrap, tid, nthreads);
 	else if (kind == K_CDF53)
-		tail_level_passes<K_CDF53, SGN>(W, wp, Tc, Tr, wrap, tid);
+		tail_level_passes<K_CDF53, SGN>(W, wp, Tc, Tr, wrap, tid, nthreads);
 	else
-		tail_level_passes<K_HAAR, SGN>(W, wp, Tc, Tr, wrap, tid);
+		tail_level_passes<K_HAAR, SGN>(W, wp, Tc, Tr, wrap, tid, nthreads);
 }
 
 __global__ __launch_bounds__(TAIL_THREADS) void k_forward_tail(const TailParams P)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	int16_t* W = smem;
-	int16_t* dense = smem + TAIL_WROWS * TAIL_WCOLS;
-	const int tid = threadIdx.x;
+	int16_t* dense = smem + P.win_elems;
+	const int tid = threadIdx.x, nthreads = blockDim.x;
 	const uint32_t p = blockIdx.x % P.channels;
 	const uint64_t inst = blockIdx.x / P.channels;
 	const uint32_t tile = (uint32_t)(inst % P.n_tiles), image = (uint32_t)(inst / P.n_tiles);
@@ -195,13 +196,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_forward_tail(const TailParams 
 			if (P.plane_tiled)
 				gsrc += (uint64_t)td.y0 * P.plane_pitch + td.x0;
 		}
-		for (int base = tid; base < wrows * wcols; base += 8 * TAIL_THREADS)
+		for (int base = tid; base < wrows * wcols; base += 8 * nthreads)
 		{
 			int16_t val[8];
 #pragma unroll
 			for (int k = 0; k < 8; k++)
 			{
-				const int idx = base + k * TAIL_THREADS;
+				const int idx = base + k * nthreads;
 				val[k] = 0;
 				if (idx < wrows * wcols)
 				{
@@ -218,14 +219,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_forward_tail(const TailParams 
 #pragma unroll
 			for (int k = 0; k < 8; k++)
 			{
-				const int idx = base + k * TAIL_THREADS;
+				const int idx = base + k * nthreads;
 				if (idx < wrows * wcols)
 					W[idx] = val[k];
 			}
 		}
 		__syncthreads();
 
-		tail_level_dispatch<+1>(L.kind, W, wp, Tc, Tr, wrap, tid);
+		tail_level_dispatch<+1>(L.kind, W, wp, Tc, Tr, wrap, tid, nthreads);
 
 		// ---- sub-bands out: C, B, D to the stream, LL to the dense array / final low-pass --------
 		int16_t* grp = tile_stream + L.grp0 + (uint64_t)p * L.gsize;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_forward_tail(const TailParams 
 		if (tid == 0)
 			grp[0] = (int16_t)q;
 		const FastDiv dT(Tc);
-		for (int idx = tid; idx < nsub; idx += TAIL_THREADS)
+		for (int idx = tid; idx < nsub; idx += nthreads)
 		{
 			const int r = dT.div(idx), c = idx - r * Tc;
 			const int16_t* cell = W + (2 * (r + ORG_R)) * wp + 2 * (c + ORG_C);
@@ -257,8 +258,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inverse_tail(const TailParams 
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t smem[];
 	int16_t* W = smem;
-	int16_t* dense = smem + TAIL_WROWS * TAIL_WCOLS;
-	const int tid = threadIdx.x;
+	int16_t* dense = smem + P.win_elems;
+	const int tid = threadIdx.x, nthreads = blockDim.x;
 	const uint32_t p = blockIdx.x % P.channels;
 	const uint64_t inst = blockIdx.x / P.channels;
 	const uint32_t tile = (uint32_t)(inst % P.n_tiles), image = (uint32_t)(inst / P.n_tiles);
@@ -278,14 +279,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inverse_tail(const TailParams 
 		const int16_t* ll = (l + 1 == (int)P.nlev) ? (tile_stream + (uint64_t)p * P.fw * P.fh) : dense;
 
 		const FastDiv dW(wcols);
-		for (int base = tid; base < wrows * wcols; base += 8 * TAIL_THREADS)
+		for (int base = tid; base < wrows * wcols; base += 8 * nthreads)
 		{
 			int16_t val[8];
 			bool hp[8];
 #pragma unroll
 			for (int k = 0; k < 8; k++)
 			{
-				const int idx = base + k * TAIL_THREADS;
+				const int idx = base + k * nthreads;
 				val[k] = 0, hp[k] = false;
 				if (idx < wrows * wcols)
 				{
@@ -310,18 +311,18 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inverse_tail(const TailParams 
 #pragma unroll
 			for (int k = 0; k < 8; k++)
 			{
-				const int idx = base + k * TAIL_THREADS;
+				const int idx = base + k * nthreads;
 				if (idx < wrows * wcols)
 					W[idx] = (hp[k] && q > 1) ? (int16_t)((int)val[k] * q) : val[k];  // lifting.c:30-40
 			}
 		}
 		__syncthreads();
 
-		tail_level_dispatch<-1>(L.kind, W, wp, Tc, Tr, wrap, tid);
+		tail_level_dispatch<-1>(L.kind, W, wp, Tc, Tr, wrap, tid, nthreads);
 
 		// ---- the level's output: next level's LL (dense LDS), or the plane / image --------------
 		const FastDiv dO(ow);
-		for (int idx = tid; idx < ow * oh; idx += TAIL_THREADS)
+		for (int idx = tid; idx < ow * oh; idx += nthreads)
 		{
 			const int y = dO.div(idx), x = idx - y * ow;
 			const int16_t v = W[(2 * ORG_R + y) * wp + 2 * ORG_C + x];

@@ -329,6 +329,39 @@ def test_fused_levels_0_and_1_forward(po):
                 os.environ[k] = v
 
 
+def test_workgroup_shapes_and_lockstep_knobs(po):
+    """AKO_HIP_LOCKSTEP (barrier every six slots, strip-major int16 units) and the number of strip pairs per workgroup
+    of the u8 kernels only change which waves share a workgroup and when they wait for each other: every combination
+    must give the oracle's bytes, on shapes with one strip, several strips, a ragged last strip, tiles and a batch."""
+    nrng = np.random.default_rng(31)
+    keys = ("AKO_HIP_LOCKSTEP", "AKO_HIP_FWD_PAIRS", "AKO_HIP_INV_PAIRS", "AKO_HIP_PATH")
+    old = {k: os.environ.get(k) for k in keys}
+    shapes = [(200, 90, 4, 0), (1000, 300, 4, 0), (1366, 200, 4, 0), (777, 131, 3, 0), (1024, 512, 4, 256), (640, 480, 1, 0)]
+    try:
+        os.environ["AKO_HIP_PATH"] = "stream"
+        for lock in (0, 1, 2, 3):
+            for pairs in ((1, 1), (2, 2), (4, 4), (2, 1), (1, 4)):
+                os.environ["AKO_HIP_LOCKSTEP"] = str(lock)
+                os.environ["AKO_HIP_FWD_PAIRS"], os.environ["AKO_HIP_INV_PAIRS"] = str(pairs[0]), str(pairs[1])
+                for (w, h, ch, tiles) in shapes:
+                    wavelet = int(nrng.integers(0, 3))
+                    wrap = int(nrng.integers(0, 4))
+                    q = int(nrng.choice([0, 11]))
+                    img = nrng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+                    s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=q // 2, tiles=tiles)
+                    ob, st = po.encode_image(s, img)
+                    assert st == 0
+                    assert np.array_equal(hip_encode_body(img, s), ob[16:]), (lock, pairs, w, h, ch, tiles, wavelet, wrap)
+                    od, os_, _ = po.decode_image(ob)
+                    assert np.array_equal(hip_decode_body(ob[16:], os_, ch, w, h), od), (lock, pairs, w, h, ch, tiles, wavelet, wrap)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_optimistic_inverse_around_its_proof_bound(po):
     """The optimistic fp32 inverse may only keep its result when no int16 wrap could have happened (input
     magnitudes <= 3560, lifted magnitudes <= 10921, ako_stream.hip.h).  Streams whose coefficients sit just
