@@ -66,7 +66,7 @@ static inline int sink_put(struct bit_sink* s, uint16_t code)
 
 static inline uint16_t value_code(int16_t c)
 {
-	const uint16_t zz = (uint16_t)(((int)c << 1) ^ ((int)c >> 15));
+	const uint16_t zz = (uint16_t)(((uint32_t)(int32_t)c << 1) ^ (uint32_t)((int32_t)c >> 15));
 	return (uint16_t)(zz + 1);
 }
 

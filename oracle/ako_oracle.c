@@ -769,7 +769,7 @@ static size_t orc_put_end(struct orc_bits* b)
 
 static inline uint16_t orc_zigzag(i16 v) /* kagari.c:169-173 */
 {
-	return (uint16_t)(((int)v << 1) ^ ((int)v >> 15));
+	return (uint16_t)(((uint32_t)(int32_t)v << 1) ^ (uint32_t)((int32_t)v >> 15));
 }
 
 static inline i16 orc_unzigzag(uint16_t v) /* kagari.c:175-178 */
