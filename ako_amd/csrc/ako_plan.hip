@@ -1564,6 +1564,63 @@ static int download_chunked(akoHipPlan* pl, void* h_dst, const void* d_src, size
 	return 0;
 }
 
+// Host -> device for a large PAGEABLE source, the mirror image of download_chunked(): a few host threads fill one pinned
+// 16 MB buffer while the other one is on the link (a plain hipMemcpy from pageable memory runs at about a quarter of the
+// link rate).  The copies are ordered on the plan's stream; returns when the last one has been issued AND has left the
+// staging buffers.
+static int upload_chunked(akoHipPlan* pl, void* d_dst, const void* h_src, size_t bytes)
+{
+	hipPointerAttribute_t attr;
+	const bool pinned = (hipPointerGetAttributes(&attr, h_src) == hipSuccess && attr.type == hipMemoryTypeHost);
+	if (!pinned)
+		(void)hipGetLastError();
+	if (pinned || bytes < 4 * DL_CHUNK)
+	{
+		HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, pl->stream));
+		return 0;
+	}
+	for (int k = 0; k < 2; k++)
+	{
+		if (!pl->pin[k] && hipHostMalloc(&pl->pin[k], DL_CHUNK, hipHostMallocDefault) != hipSuccess)
+			return fail(AKO_NO_ENOUGH_MEMORY, "hipHostMalloc(upload staging) failed%s%s");
+		if (!pl->pin_done[k])
+			HIP_TRY(hipEventCreateWithFlags(&pl->pin_done[k], hipEventDisableTiming));
+	}
+	const size_t n = (bytes + DL_CHUNK - 1) / DL_CHUNK;
+	for (size_t k = 0; k < n; k++)
+	{
+		HIP_TRY(hipEventSynchronize(pl->pin_done[k & 1]));  // whatever copy last used this buffer has left it
+		const size_t off = k * DL_CHUNK, len = (off + DL_CHUNK <= bytes) ? DL_CHUNK : bytes - off;
+		uint8_t* dst = (uint8_t*)pl->pin[k & 1];
+		const uint8_t* src = (const uint8_t*)h_src + off;
+		const size_t part = ((len / DL_THREADS) + 63) & ~(size_t)63;
+		std::thread helpers[DL_THREADS - 1];
+		int started = 0;
+		for (int t = 1; t < DL_THREADS; t++)
+		{
+			const size_t lo = (size_t)t * part;
+			if (lo >= len)
+				break;
+			const size_t cnt = (lo + part <= len) ? part : len - lo;
+			try
+			{
+				helpers[started] = std::thread([=] { memcpy(dst + lo, src + lo, cnt); });
+				started++;
+			}
+			catch (...)
+			{
+				memcpy(dst + lo, src + lo, cnt);
+			}
+		}
+		memcpy(dst, src, part < len ? part : len);
+		for (int t = 0; t < started; t++)
+			helpers[t].join();
+		HIP_TRY(hipMemcpyAsync((uint8_t*)d_dst + off, dst, len, hipMemcpyHostToDevice, pl->stream));
+		HIP_TRY(hipEventRecord(pl->pin_done[k & 1], pl->stream));
+	}
+	return 0;
+}
+
 static int ensure_staging(akoHipPlan* pl)
 {
 	if (!pl->d_img)
@@ -1966,9 +2023,11 @@ static int kagari_expand(akoHipPlan* pl, const int16_t* h_literals, size_t n_lit
 		k->run_record_capacity = n_runs + n_runs / 4 + 1024;
 	}
 	hipStream_t st = pl->stream;
-	HIP_TRY(hipMemcpyAsync(k->d_literals, h_literals, n_literals * 2, hipMemcpyHostToDevice, st));
+	if (int rc = upload_chunked(pl, k->d_literals, h_literals, n_literals * 2))
+		return rc;
 	if (n_runs)
-		HIP_TRY(hipMemcpyAsync(k->d_runs, h_runs, n_runs * sizeof(KgRun), hipMemcpyHostToDevice, st));
+		if (int rc = upload_chunked(pl, k->d_runs, h_runs, n_runs * sizeof(KgRun)))
+			return rc;
 	int16_t* out = static_cast<int16_t*>(d_streams) + image * pl->stream_values;
 	const uint32_t blocks = (uint32_t)((pl->stream_values + KG_CHUNK - 1) / KG_CHUNK);
 	hipLaunchKernelGGL(k_kg_expand, dim3(blocks), dim3(KG_THREADS), 0, st, (const int16_t*)k->d_literals,
