@@ -132,6 +132,8 @@ struct Tuning
 	int seg_rows_mid = 0, seg_rows_mid_inv = 0;  // AKO_HIP_SEG_ROWS_MID / _MID_INV: same for int16 levels of 1024..2047
 	                                             // columns, forward / inverse kernels
 	int floor_big = 24;    // AKO_HIP_FLOOR_BIG: fewest rows per segment of levels with >= 2048 columns
+	int tail_many = 16;    // AKO_HIP_TAIL_MANY: largest level the tail takes when a launch has many planes (tiled images;
+	                       // 16384 x 16384 in 256-px tiles: 8 -> 89, 16 -> 95, 32 -> 90, 64 -> 51 Gpx/s)
 	int u8_waves = 0;      // AKO_HIP_U8_WAVES: waves a u8 level launch aims at (0 = two rounds of resident waves)
 	int lockstep = 3;      // AKO_HIP_LOCKSTEP: StreamGeom::lockstep (bit 0 barrier every six slots, bit 1 strip-major units)
 	int fwd_pairs = 2;     // AKO_HIP_FWD_PAIRS: pairs of waves (= neighbouring strips) per workgroup of the u8 forward kernel
@@ -159,6 +161,9 @@ struct Tuning
 		t.staged = num("AKO_HIP_STAGED", 1) != 0;
 		t.deep = num("AKO_HIP_DEEP", 1) != 0;
 		t.u8_waves = num("AKO_HIP_U8_WAVES", 0);
+		t.tail_many = num("AKO_HIP_TAIL_MANY", 16);
+		if (t.tail_many < 8 || t.tail_many > TAIL_MAX)
+			t.tail_many = 16;
 		t.floor_big = num("AKO_HIP_FLOOR_BIG", 24);
 		if (t.floor_big < 2)
 			t.floor_big = 2;
@@ -611,7 +616,7 @@ size_t tail_start(const akoHipPlan* pl, const Group& g)
 		return nl;
 	uint32_t lim = (engine == 2) ? (uint32_t)SEG_TAIL_MAX : (uint32_t)TAIL_MAX;
 	if (many_planes(pl) && path_mode(pl) != PATH_GENERIC)
-		lim = 8;  // see stream_eligible(): only what the streaming kernels cannot take
+		lim = (uint32_t)pl->tune.tail_many;  // see stream_eligible(): only what the streaming kernels cannot take
 	if (pl->tune.tail_max >= 4 && (uint32_t)pl->tune.tail_max < lim)  // tuning aid: hand smaller levels only to the tail
 		lim = (uint32_t)pl->tune.tail_max;
 	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
@@ -1167,7 +1172,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;
