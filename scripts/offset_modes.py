@@ -12,12 +12,13 @@ s = api.settings(wavelet=0, compression=2, q=16, g=16)
 plan = api.Plan(s, 4, w, h)
 nbytes_img = w * h * 4
 nbytes_str = plan.new_streams().numel() * 2
-pool = torch.empty(nbytes_img * 2 + nbytes_str + (64 << 20), dtype=torch.uint8, device="cuda")
+pool = torch.empty(nbytes_img * 2 + nbytes_str + (1200 << 20), dtype=torch.uint8, device="cuda")
 host = torch.from_numpy(img).reshape(-1)
 def carve(off, n, dtype):
     t = pool[off:off + n]
     return t.view(dtype)
-for delta in [0, 256, 1024, 4096, 16384, 65536, 1 << 18, 1 << 20, (1 << 20) + 4096, 3 << 19, 1 << 21, 0]:
+deltas = [int(x) for x in os.environ["DELTAS_MB"].split(",")] if os.environ.get("DELTAS_MB") else None
+for delta in ([d << 20 for d in deltas] if deltas else [0, 256, 1024, 4096, 16384, 65536, 1 << 18, 1 << 20, (1 << 20) + 4096, 3 << 19, 1 << 21, 0]):
     o_img = 0
     o_str = nbytes_img + (8 << 20) + delta
     o_back = o_str + nbytes_str + (8 << 20) + delta
