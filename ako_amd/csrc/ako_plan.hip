@@ -473,7 +473,16 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		                            : (L.tw >= 1024) ? 12
 		                                             : (pl->tune.seg_rows_small > 0 ? (uint32_t)pl->tune.seg_rows_small : 2);
 		if (seg_rows < floor_rows)
+		{
 			seg_rows = floor_rows;
+			// the floor decides: if the launch then is a little more than ONE round of resident waves (int16 kernels:
+			// 5 per SIMD = 5120), its second round would run almost empty -- make it exactly one round instead
+			// (level 1 of the 8192 x 8192 image: 86 segments = 6192 waves -> 71 = 5112: 88 / 86 -> 82 / 79 us)
+			const uint64_t resident = u8 ? 4096 : 5120;
+			const uint64_t n_segs = (L.th + seg_rows - 1) / seg_rows;
+			if (n_segs * per_seg > resident && n_segs * per_seg < resident * 8 / 5 && resident / per_seg >= 1)
+				seg_rows = (uint32_t)((L.th + resident / per_seg - 1) / (resident / per_seg));
+		}
 	}
 	if (seg_rows > L.th)
 		seg_rows = L.th;
