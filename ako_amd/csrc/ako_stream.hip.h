@@ -1460,7 +1460,8 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 }
 
 template <int KIND, int NPL, bool U8, bool NARROW, int DEEP = 0>
-__global__ __launch_bounds__(THREADS) void k_forward_stream(const LevelParams P, const StreamGeom G)
+// (5 waves per SIMD = 102 VGPRs: the small-level launches are sized as one round of 5 x 1024 waves, ako_plan.hip)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_forward_stream(const LevelParams P, const StreamGeom G)
 {
 	const UnitId id = decode_unit(P, G);
 	if (!id.valid)
