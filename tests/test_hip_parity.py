@@ -640,6 +640,47 @@ def test_api_tiled_kagari_and_events(po, golden_sums):
     assert ev == [(t, tiles, e) for t in range(tiles) for e in (5, 6, 3, 4, 1, 2)]   # decode.c:145-207 order
 
 
+def test_api_large_kagari_blobs_take_the_threaded_decoder_paths(po):
+    """Decoder routes that only large inputs reach: one block parsed by several threads (>= 128 KiB), windows of tile
+    lists merged by the worker threads (>= 65536 literals per window, several windows), token lists kept for the
+    next call, the huge-page advice on the result (>= 16 MB) -- same pixels as the oracle, twice in a row, and a
+    damaged block inside a late window still fails like the oracle's decoder does."""
+    import ctypes as C
+
+    L = api.lib()
+    L.akoHostKagariParallelStats.restype = None
+    acc, back = C.c_size_t(0), C.c_size_t(0)
+    nrng = np.random.default_rng(606)
+    w, h = 2304, 1856
+    # noise over a smooth image: dense bit-streams (about 1.5 literals per sample) that still shrink
+    base = po.gen_image(0, w, h).astype(np.int16)
+    img = np.clip(base + nrng.integers(-6, 7, base.shape), 0, 255).astype(np.uint8)
+    for tiles in (0, 64):
+        s = po.settings(wavelet=0, compression=0, q=3, g=0, tiles=tiles)
+        blob, st = po.encode_image(s, img)
+        assert st == 0
+        want, _, _ = po.decode_image(blob)
+        L.akoHostKagariParallelStats(C.byref(acc), C.byref(back))
+        before = acc.value
+        for _ in range(2):
+            got, _ = api.decode(blob)
+            assert np.array_equal(got, want), tiles
+            del got
+        L.akoHostKagariParallelStats(C.byref(acc), C.byref(back))
+        if tiles == 0:
+            assert blob.size > (1 << 20) and acc.value - before == 2   # the single block went through the threads both times
+        else:
+            assert (w // 64) * (h // 64) > 2 * 16 * 8                   # more than two windows of tiles
+            bad = blob.copy()
+            bad[blob.size - blob.size // 5] ^= 0x10                     # inside a tile of the last window
+            od, ost, _ = po.decode_image(bad)
+            try:
+                gd, _ = api.decode(bad)
+                assert od is not None and np.array_equal(gd, od)
+            except api.AkoError as e:
+                assert od is None, e
+
+
 def test_api_matches_oracle_on_random_settings(po):
     rng = random.Random(11)
     nrng = np.random.default_rng(12)
