@@ -1090,7 +1090,10 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 					Launch LO{pl, 1};
 					if (int rc = LO.begin())
 						return rc;
-					launch_inverse_u8<true>(L.kind, P, G, (uint32_t)blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
+					if (pl->tune.dbg & 16)
+						hipLaunchKernelGGL(k_inverse_stream_u8_memonly, dim3((uint32_t)blocks), dim3(128 * (uint32_t)pl->tune.inv_pairs), 0, pl->stream, P, G);
+					else
+						launch_inverse_u8<true>(L.kind, P, G, (uint32_t)blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 					snprintf(name, sizeof name, "inv_stream_%s_u8", kind_name(L.kind));
 					const uint64_t smp = (uint64_t)L.cw * L.ch * pl->channels * insts;
 					const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;

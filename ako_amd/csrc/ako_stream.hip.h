@@ -1644,7 +1644,7 @@ struct InvRaw
 constexpr float OPT_INPUT_BOUND = 3560.0f;
 constexpr float OPT_OUTPUT_BOUND = 10921.0f;
 
-template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE, int DEEP, int PF = 2>
+template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE, int DEEP, int PF = 2, bool MEMONLY = false>
 __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
                                                     const LaneCols& lc, int lane, uint4 (*xbuf)[2][2][64])
 {
@@ -1724,6 +1724,13 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	auto fetch = [&](int v, Raw& raw) {
 		const int m = max(VEDGE ? map_index(v, Tr, wrap) : v, 0);
 		const uint32_t row_g = (uint32_t)m * (uint32_t)Tc * 2u, row_l = (uint32_t)m * ll_pitch * 2u;
+		if (MEMONLY && (P.dbg & 64))  // measurement aid: stores only
+		{
+#pragma unroll
+			for (int p = 0; p < NPL; p++)
+				raw.ll[p] = raw.c[p] = raw.b[p] = raw.d[p] = (uint32_t)v;
+			return;
+		}
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
 		{
@@ -1742,6 +1749,20 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 			const bool zero_row = VEDGE && (wrap == W_ZERO) && ((unsigned)v >= (unsigned)Tr);
 
 			const int r = v - 3;
+			if constexpr (MEMONLY && U8 && NPL == 2)
+			{
+				// measurement aid (AKO_HIP_DBG bit 4): the slot's loads and its pixel store with no arithmetic and no
+				// exchange between them (garbage output); bit 5 loads only, bit 6 stores only
+				typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+				const int y = 2 * r + pair;
+				const bool row_ok = (r >= r_lo) && (r < r_hi) && (y < oh) && !(P.dbg & 32);
+				const uint32_t s_row = row_ok ? (uint32_t)y * (uint32_t)out_pitch : OOB;
+				__builtin_amdgcn_raw_buffer_store_b128(u32x4{raw.ll[0] ^ raw.c[0], raw.b[0] ^ raw.d[0], raw.ll[1] ^ raw.c[1], raw.b[1] ^ raw.d[1]},
+				                                       rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
+				if ((P.dbg & 32) && (raw.ll[0] ^ raw.c[0] ^ raw.b[1] ^ raw.d[1]) == 0x12345678u)  // keeps the loads alive
+					__builtin_amdgcn_raw_buffer_store_b32(raw.b[0], rs_img, px_lane_off, 0, 0);
+				return;
+			}
 			const bool store_row = (r >= r_lo) && (r < r_hi) && store_lane;
 			V out[2][NPL][4];  // [row parity][plane][E0 O0 E1 O1]
 #pragma unroll
@@ -2042,6 +2063,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 		else
 			inverse_stream_body<KIND, 2, true, OPT, false, false, 0, 2>(P, G, id, lc, lane, xbuf);
 	}
+}
+
+// measurement aid (AKO_HIP_DBG bit 4): the u8 inverse level kernel's loads and stores alone
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_inverse_stream_u8_memonly(const LevelParams P, const StreamGeom G)
+{
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	inverse_stream_body<K_DD137, 2, true, true, false, true, 0, 2, true>(P, G, id, lc, lane, nullptr);
 }
 
 }  // namespace ako
