@@ -477,6 +477,34 @@ struct UnitId
 	bool valid;
 };
 
+template <typename T>
+__device__ __forceinline__ void split_unit(T u, uint32_t blk, const LevelParams& P, const StreamGeom& G, UnitId& id)
+{
+	if ((G.lockstep & 2) && P.plane_groups != 2)
+	{
+		id.strip = (uint32_t)(u % (T)G.strips);
+		u /= (T)G.strips;
+		id.pg = (uint32_t)(u % (T)P.plane_groups);
+		u /= (T)P.plane_groups;
+	}
+	else
+	{
+		id.pg = (uint32_t)(u % (T)P.plane_groups);
+		// the two waves of a u8 pair do unequal work (forward: Y + Cg against Co + alpha) and wave w of a
+		// workgroup runs on SIMD w % 4: swap the roles in every other workgroup (by bit parity, which does not
+		// correlate with any round-robin placement) so that every SIMD gets both kinds
+		if (P.plane_groups == 2)
+			id.pg ^= (uint32_t)(__builtin_popcount(blk) & 1);
+		u /= (T)P.plane_groups;
+		id.strip = (uint32_t)(u % (T)G.strips);
+		u /= (T)G.strips;
+	}
+	id.seg = (uint32_t)(u % (T)G.segs);
+	u /= (T)G.segs;
+	id.tile = (uint32_t)(u % (T)P.n_tiles);
+	id.image = (uint32_t)(u / (T)P.n_tiles);
+}
+
 __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const StreamGeom& G)
 {
 	UnitId id;
@@ -491,33 +519,16 @@ __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const Stream
 	const uint32_t per_xcd = gridDim.x >> 3;
 	if (!(P.dbg & 4) && blk < (per_xcd << 3))
 		blk = (blk & 7) * per_xcd + (blk >> 3);
-	uint64_t u = (uint64_t)blk * (blockDim.x >> 6) + wave;
+	const uint64_t u = (uint64_t)blk * (blockDim.x >> 6) + wave;
 	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
 	id.valid = u < total;
-
-	if ((G.lockstep & 2) && P.plane_groups != 2)
-	{
-		id.strip = (uint32_t)(u % G.strips);
-		u /= G.strips;
-		id.pg = (uint32_t)(u % P.plane_groups);
-		u /= P.plane_groups;
-	}
+	// 64-bit divisions are loops of several hundred scalar instructions each on this target -- a few microseconds of
+	// every wave's start, which the small levels (a wave there does ~1500 instructions of real work) feel; unit
+	// counts practically always fit 32 bits, where a division is ~25 instructions
+	if (total <= 0xFFFFFFFFull)
+		split_unit<uint32_t>((uint32_t)u, blk, P, G, id);
 	else
-	{
-		id.pg = (uint32_t)(u % P.plane_groups);
-		// the two waves of a u8 pair do unequal work (forward: Y + Cg against Co + alpha) and wave w of a
-		// workgroup runs on SIMD w % 4: swap the roles in every other workgroup (by bit parity, which does not
-		// correlate with any round-robin placement) so that every SIMD gets both kinds
-		if (P.plane_groups == 2)
-			id.pg ^= (uint32_t)(__builtin_popcount(blk) & 1);
-		u /= P.plane_groups;
-		id.strip = (uint32_t)(u % G.strips);
-		u /= G.strips;
-	}
-	id.seg = (uint32_t)(u % G.segs);
-	u /= G.segs;
-	id.tile = (uint32_t)(u % P.n_tiles);
-	id.image = (uint32_t)(u / P.n_tiles);
+		split_unit<uint64_t>(u, blk, P, G, id);
 	return id;
 }
 
