@@ -16,8 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libako.so")
 OBJ = os.path.join(HERE, "csrc", "build")
 
-HIP_SOURCES = ["ako_plan.hip"]
-HIP_HEADERS = ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_tail.hip.h", "ako_kagari.hip.h", "ako_requant.hip.h"]
+# translation units of device code and the headers each one includes (they build in parallel: ako_plan.hip alone takes minutes)
+HIP_SOURCES = {
+    "ako_plan.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_tail.hip.h", "ako_kagari.hip.h", "ako_requant.hip.h", "ako_fused.h"],
+    "ako_fused.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_fused.h", "ako_fused.hip.h"],
+}
 C_SOURCES = ["host/ako_quant.c", "host/ako_head.c", "host/ako_misc.c", "host/ako_kagari.c", "host/ako_codec.c",
              "host/ako_synth.c", "host/ako_batch.c"]
 C_HEADERS = ["host/ako_host.h", "../../include/ako.h", "../../include/ako_hip.h"]
@@ -41,17 +44,23 @@ def _run(cmd: list[str]) -> None:
 def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
     os.makedirs(OBJ, exist_ok=True)
     objs = []
-    hip_deps = [os.path.join(CSRC, h) for h in HIP_HEADERS + C_HEADERS]
-    for src in HIP_SOURCES:
+    jobs = []
+    for src, headers in HIP_SOURCES.items():
         o = os.path.join(OBJ, os.path.basename(src) + ".o")
+        hip_deps = [os.path.join(CSRC, h) for h in headers + C_HEADERS]
         if force or _stale(o, [os.path.join(CSRC, src)] + hip_deps):
             # -fno-slp-vectorize: keeps hipcc from fusing scalar f32 adds into v_pk_add_f32, which costs
             # about two plain adds on gfx950 (MI355X_MICROARCH.md, cycle constants) and needs register pairs
-            _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                  "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"] + (extra_hip_flags or []) +
-                 os.environ.get("AKO_HIPCC_EXTRA", "").split() +  # experiments only
-                 ["-c", os.path.join(CSRC, src), "-o", o])
+            cmd = ([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                    "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"] + (extra_hip_flags or []) +
+                   os.environ.get("AKO_HIPCC_EXTRA", "").split() +  # experiments only
+                   ["-c", os.path.join(CSRC, src), "-o", o])
+            print(" ".join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
         objs.append(o)
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
     c_deps = [os.path.join(CSRC, h) for h in C_HEADERS]
     for src in C_SOURCES:
         o = os.path.join(OBJ, os.path.basename(src) + ".o")

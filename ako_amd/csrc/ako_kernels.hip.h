@@ -599,6 +599,7 @@ __device__ __forceinline__ int16_t* format_plane_address(const FormatParams& P, 
 	return P.stream + (uint64_t)image * P.stream_stride + td.stream_off + i;
 }
 
+template <int UNUSED = 0>  // (a template so that every translation unit including this header may hold it)
 __global__ __launch_bounds__(THREADS) void k_format_forward(const FormatParams P)
 {
 	const uint64_t npx = (uint64_t)P.tile_w * P.tile_h;
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(THREADS) void k_format_forward(const FormatParams P
 		out[k * kstride] = (int16_t)v[k];
 }
 
+template <int UNUSED = 0>
 __global__ __launch_bounds__(THREADS) void k_format_inverse(const FormatParams P)
 {
 	const uint64_t npx = (uint64_t)P.tile_w * P.tile_h;

@@ -10,6 +10,7 @@
 #include "ako_tail.hip.h"
 #include "ako_kagari.hip.h"
 #include "ako_requant.hip.h"
+#include "ako_fused.h"
 
 #include "../../include/ako_hip.h"
 
@@ -140,6 +141,10 @@ struct Tuning
 	int inv_pairs = 2;     // AKO_HIP_INV_PAIRS: same for the u8 inverse kernel (1, 2 or 4)
 	bool fuse = false;     // AKO_HIP_FUSE=1: forward level 1 inside the level-0 strip walk (k_forward_fused_u8) instead of a launch of
 	                       // its own.  Bit-exact and parity-tested, but off by default: measured slower
+	int fuse2 = 3;         // AKO_HIP_FUSE2: levels 0 and 1 of eligible RGBA plans in one workgroup walk, the level-0 low-pass plane
+	                       // handed over through LDS (ako_fused.hip.h): bit 0 forward, bit 1 inverse
+	int f2_rows = 0;       // AKO_HIP_F2_ROWS: rows per segment of those kernels (0 = one round of workgroups)
+	int f2_edge = -1;      // AKO_HIP_F2_EDGE: rows of their first / last segment (-1 = chosen, 0 = like the others)
 	uint32_t dbg = 0;      // AKO_HIP_DBG bits (kernel side experiments)
 
 	static Tuning from_env()
@@ -177,7 +182,12 @@ struct Tuning
 		if (t.inv_pairs != 1 && t.inv_pairs != 4)
 			t.inv_pairs = 2;
 		t.fuse = num("AKO_HIP_FUSE", 0) != 0;
+		t.fuse2 = num("AKO_HIP_FUSE2", 3) & 3;
+		t.f2_rows = num("AKO_HIP_F2_ROWS", 0);
+		t.f2_edge = num("AKO_HIP_F2_EDGE", -1);
+#ifdef AKO_MEASURE  // measurement builds only: the shipped library does not read AKO_HIP_DBG
 		t.dbg = (uint32_t)num("AKO_HIP_DBG", 0);
+#endif
 		return t;
 	}
 };
@@ -541,6 +551,99 @@ StreamGeom fused_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wav
 	return G;
 }
 
+uint64_t scratch_plane_elems(const Group& g, int which);
+
+// Levels 0 and 1 of a u8 RGBA plan in one workgroup walk per direction (ako_fused.hip.h): shapes without a phantom
+// column or row at either level, the usual colour mode (YCoCg / YCoCg_Q without the discard rule), no REPEAT border (a
+// wrapped tap would need the other end of the row / column, which another workgroup holds), the same wavelet at both
+// levels (DD13/7 or CDF5/3), and both levels outside the in-LDS tail.
+bool fused2_eligible(const akoHipPlan* pl, const Group& g, bool u8_level0, size_t lt, int direction_bit)
+{
+	if (!(pl->tune.fuse2 & direction_bit) || !u8_level0 || pl->channels != 4 || g.levels.size() < 2 || lt < 2)
+		return false;
+	const LevelGeom &L0 = g.levels[0], &L1 = g.levels[1];
+	if (pl->s.wrap == AKO_WRAP_REPEAT || pl->s.discard_non_visible)
+		return false;
+	if (pl->s.color != AKO_COLOR_YCOCG && pl->s.color != AKO_COLOR_YCOCG_Q)
+		return false;
+	if ((L0.cw % 8) != 0 || (L0.ch % 4) != 0 || L0.kind != L1.kind || L0.kind == K_HAAR)
+		return false;
+	if (!stream_eligible(pl, L0, true) || !stream_eligible(pl, L1, false))
+		return false;
+	if (g.tile_values * 2 >= 0xFFF00000ull)
+		return false;
+	// narrow levels leave most of a workgroup's six strips without columns
+	const uint32_t min_cols = (path_mode(pl) == PATH_STREAM) ? 16 : 512;
+	return L0.tw >= min_cols && L0.th >= 12;
+}
+
+void fill_f2(F2Params& F, const akoHipPlan* pl, const Group& g, void* d_images, void* d_streams, int net_cols)
+{
+	const LevelGeom &L0 = g.levels[0], &L1 = g.levels[1];
+	memset(&F, 0, sizeof F);
+	F.img = (uint8_t*)d_images;
+	F.img_stride = (uint64_t)pl->w * pl->h * 4;
+	F.img_pitch = (uint32_t)pl->w;
+	F.stream = (int16_t*)d_streams;
+	F.stream_stride = pl->stream_values;
+	F.tiles = g.d_tiles, F.n_tiles = (uint32_t)g.tiles.size(), F.batch = (uint32_t)pl->batch;
+	F.Tc = L0.tw, F.Tr = L0.th;
+	F.wrap = (int)pl->s.wrap, F.color = (int)pl->s.color;
+	for (int l = 0; l < 2; l++)
+	{
+		const LevelGeom& L = g.levels[l];
+		for (int p = 0; p < 4; p++)
+			F.lv[l].grp_off[p] = (uint32_t)L.grp_off[p];
+		for (int m = 0; m < 2; m++)
+		{
+			F.lv[l].q[m] = L.q[m];
+			F.lv[l].gate[m] = (float)L.g[m];
+			F.lv[l].rq[m] = (float)((1.0 / (double)(L.q[m] < 1 ? 1 : L.q[m])) * (1.0 + 1e-6));
+		}
+	}
+	if (g.levels.size() == 2)
+	{
+		F.ll1_in_stream = 1;
+		for (int p = 0; p < 4; p++)
+			F.lp_off[p] = (uint32_t)g.lp_off[p];
+	}
+	else
+	{
+		F.ll1 = pl->scratch[1];
+		F.ll1_pitch = L1.tw;
+		F.ll1_plane_stride = (uint32_t)scratch_plane_elems(g, 1);
+		F.ll1_inst_stride = (uint64_t)F.ll1_plane_stride * 4;
+	}
+	F.groups = (L0.tw + (uint32_t)net_cols - 1) / (uint32_t)net_cols;
+	// row segments (every boundary a multiple of 6): one round of workgroups -- a workgroup fills a CU -- unless told otherwise
+	const uint64_t insts = (uint64_t)g.tiles.size() * pl->batch;
+	uint32_t S = (uint32_t)pl->tune.f2_rows;
+	if (S == 0)
+	{
+		uint64_t segs = 256 / ((uint64_t)F.groups * insts);
+		if (segs < 1)
+			segs = 1;
+		S = (uint32_t)((L0.th + segs - 1) / segs);
+	}
+	S = ((S + 5) / 6) * 6;
+	if (S < 24)
+		S = 24;
+	uint32_t E = (pl->tune.f2_edge >= 0) ? (uint32_t)pl->tune.f2_edge : ((S * 5 / 8 + 5) / 6) * 6;
+	E = ((E + 5) / 6) * 6;
+	F.seg_rows = S;
+	if (E == 0 || E >= S || L0.th < 2 * E + 24)
+	{
+		F.edge_rows = 0, F.last_lo = 0;
+		F.segs = (L0.th + S - 1) / S;
+	}
+	else
+	{
+		F.edge_rows = E;
+		F.last_lo = ((L0.th - E) / 6) * 6;
+		F.segs = 2 + (F.last_lo - E + S - 1) / S;
+	}
+}
+
 // int16 levels whose segments fit: every row slot of a wave's segment is fetched before the first is used
 int deep_prefetch(const akoHipPlan* pl, const StreamGeom& G, bool u8)
 {
@@ -778,9 +881,9 @@ int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream
 #undef AKO_PLANES4
 	}
 	else if (decode)
-		hipLaunchKernelGGL(k_format_inverse, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
+		hipLaunchKernelGGL(k_format_inverse<>, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
 	else
-		hipLaunchKernelGGL(k_format_forward, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
+		hipLaunchKernelGGL(k_format_forward<>, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, F);
 	const uint64_t units = npx * pl->channels * g.tiles.size() * pl->batch;
 	return L.end(decode ? (planar ? "planes_to_u8" : "format_inverse") : (planar ? "u8_to_planes" : "format_forward"), 0,
 	             (uint32_t)gi, units, decode ? units * 2 : units, decode ? units : units * 2);
@@ -846,6 +949,28 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			fill_common(P, pl, g, L);
 			P.stream = (int16_t*)d_streams;
 			const bool u8 = (l == 0) && !planes && !staged;
+			if (l == 0 && fused2_eligible(pl, g, u8, lt, 1))
+			{
+				// levels 0 and 1 in one workgroup walk: level 0's low-pass plane goes from wave to wave through LDS
+				const LevelGeom& L1 = g.levels[1];
+				F2Params F;
+				fill_f2(F, pl, g, (void*)d_images, d_streams, F2_GNET);
+				if (int rc = check_blocks((uint64_t)F.groups * F.segs * insts))
+					return rc;
+				Launch LF{pl, 0};
+				if (int rc = LF.begin())
+					return rc;
+				akoFused2ForwardLaunch(L.kind, F, pl->stream);
+				char fname[48];
+				snprintf(fname, sizeof fname, "fwd_fused2_%s_u8", kind_name(L.kind));
+				const uint64_t smp0 = (uint64_t)L.cw * L.ch * pl->channels * insts;
+				const uint64_t out0 = ((uint64_t)3 * L.tw * L.th + 1) * pl->channels * insts;
+				const uint64_t out1 = ((uint64_t)4 * L1.tw * L1.th + 1) * pl->channels * insts;
+				if (int rc = LF.end(fname, 0, (uint32_t)gi, smp0, smp0, (out0 + out1) * 2))
+					return rc;
+				l = 1;  // level 1 is done
+				continue;
+			}
 			if (l == 0 && lt >= 2 && fuse_eligible(pl, g, u8))
 			{
 				// levels 0 and 1 in one strip walk: level 0's low-pass plane is never written
@@ -947,9 +1072,14 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				const int deep = deep_prefetch(pl, G, u8);
 				if (int rc = LA.begin())
 					return rc;
+#ifdef AKO_MEASURE
 				if (u8 && (pl->tune.dbg & 16))
 					hipLaunchKernelGGL(k_forward_stream_u8_memonly, dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
-				else if (u8)
+				else if (!u8 && (pl->tune.dbg & 16))
+					hipLaunchKernelGGL(k_forward_stream_i16_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+				else
+#endif
+				if (u8)
 				{
 					if (L.kind == K_DD137)
 						hipLaunchKernelGGL((k_forward_stream_u8<K_DD137>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
@@ -958,8 +1088,6 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					else
 						hipLaunchKernelGGL((k_forward_stream_u8<K_HAAR>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
 				}
-				else if (pl->tune.dbg & 16)
-					hipLaunchKernelGGL(k_forward_stream_i16_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_forward_stream<1, false, DEEP_SLOTS_SHORT>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep)
@@ -1019,12 +1147,43 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 		if (staged)
 			if (int rc = ensure_planes0(pl))
 				return rc;
+		// levels 1 and 0 in one workgroup walk (optimistic fp32 pipeline, ako_fused.hip.h); the exact kernels of both levels
+		// are launched behind it and return at once unless it raised the overflow flag
+		const bool f2inv = pl->tune.opt && fused2_eligible(pl, g, !planes && !staged, lt, 2);
+		int32_t* f2_flag = nullptr;
+		int32_t f2_gen = 0;
 		for (size_t l = lt; l-- > 0;)
 		{
 			const LevelGeom& L = g.levels[l];
 			LevelParams P;
 			fill_common(P, pl, g, L);
 			P.stream = (int16_t*)d_streams;
+			if (l == 1 && f2inv)
+			{
+				F2Params F;
+				fill_f2(F, pl, g, d_images, (void*)d_streams, F2I_GNET);
+				if (int rc = check_blocks((uint64_t)F.groups * F.segs * insts))
+					return rc;
+				if (pl->ovf_gen == INT32_MAX)
+				{
+					HIP_TRY(hipMemsetAsync(pl->d_flags, 0, 64 * sizeof(int32_t), pl->stream));
+					pl->ovf_gen = 0;
+				}
+				F.ovf_flag = f2_flag = pl->d_flags + (gi * 8) % 64;
+				F.ovf_gen = f2_gen = ++pl->ovf_gen;
+				Launch LF{pl, 1};
+				if (int rc = LF.begin())
+					return rc;
+				akoFused2InverseLaunch(L.kind, F, pl->stream);
+				char fname[48];
+				snprintf(fname, sizeof fname, "inv_fused2_%s_u8", kind_name(L.kind));
+				const LevelGeom& L0 = g.levels[0];
+				const uint64_t smp0 = (uint64_t)L0.cw * L0.ch * pl->channels * insts;
+				const uint64_t in0 = ((uint64_t)3 * L0.tw * L0.th + 1) * pl->channels * insts;
+				const uint64_t in1 = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
+				if (int rc = LF.end(fname, 0, (uint32_t)gi, smp0, (in0 + in1) * 2, smp0))
+					return rc;
+			}
 			const bool u8 = (l == 0) && !planes && !staged;
 			P.planes_per_wg = u8 ? (uint32_t)(pl->channels < 4 ? pl->channels : 4) : 1;
 			P.plane_groups = (uint32_t)((pl->channels + P.planes_per_wg - 1) / P.planes_per_wg);
@@ -1074,8 +1233,11 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 					return rc;
 				// u8 side: optimistic fp32 launch, then the exact kernel which only works if the first one
 				// raised the overflow flag (AKO_HIP_OPT=0 runs the exact kernel alone)
+				const bool behind_fused = f2inv && l <= 1;  // exact kernel only, behind the two-level launch
+				if (behind_fused)
+					P.ovf_flag = f2_flag, P.ovf_gen = f2_gen;
 				const bool optimistic = u8 && pl->tune.opt;
-				if (optimistic)
+				if (optimistic && !behind_fused)
 				{
 					const size_t slot = (gi * 8 + l) % 64;
 					// the flag is never reset: an optimistic launch raises it to its generation number (they only
@@ -1090,9 +1252,11 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 					Launch LO{pl, 1};
 					if (int rc = LO.begin())
 						return rc;
+#ifdef AKO_MEASURE
 					if (pl->tune.dbg & 16)
 						hipLaunchKernelGGL(k_inverse_stream_u8_memonly, dim3((uint32_t)blocks), dim3(128 * (uint32_t)pl->tune.inv_pairs), 0, pl->stream, P, G);
 					else
+#endif
 						launch_inverse_u8<true>(L.kind, P, G, (uint32_t)blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 					snprintf(name, sizeof name, "inv_stream_%s_u8", kind_name(L.kind));
 					const uint64_t smp = (uint64_t)L.cw * L.ch * pl->channels * insts;
@@ -1111,7 +1275,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				else
 					launch_inverse_stream<1, false, false, 0>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				snprintf(name, sizeof name, "inv_stream_%s%s%s", kind_name(L.kind), u8 ? "_u8" : (deep ? "_deep" : ""),
-				         optimistic ? "_exact_if_flagged" : "");
+				         (optimistic || behind_fused) ? "_exact_if_flagged" : "");
 			}
 			else
 			{
@@ -1184,7 +1348,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;

@@ -1528,6 +1528,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5))) vo
 #endif
 constexpr int U8_RING = AKO_U8_RING;  // row slots the u8 forward kernel fetches ahead (2, 3 or 6)
 
+// Measurement builds only (-DAKO_MEASURE, scripts/build_variant.sh): the shipped library neither holds these kernels nor
+// reads AKO_HIP_DBG.
+#ifdef AKO_MEASURE
 // measurement aid: the interior body's loads and stores without its arithmetic, every unit (AKO_HIP_DBG bit 4)
 __global__ __launch_bounds__(THREADS) void k_forward_stream_u8_memonly(const LevelParams P, const StreamGeom G)
 {
@@ -1548,6 +1551,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream_i16_memonly(const Le
 	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	forward_stream_body<K_DD137, 1, false, false, false, true, 0, false, 2, 0, true>(P, G, id, lc, lane);
 }
+#endif  // AKO_MEASURE
 
 template <int KIND>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_forward_stream_u8(const LevelParams P, const StreamGeom G)
@@ -2076,6 +2080,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	}
 }
 
+#ifdef AKO_MEASURE
 // measurement aid (AKO_HIP_DBG bit 4): the u8 inverse level kernel's loads and stores alone
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_inverse_stream_u8_memonly(const LevelParams P, const StreamGeom G)
 {
@@ -2086,5 +2091,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	inverse_stream_body<K_DD137, 2, true, true, false, true, 0, 2, true>(P, G, id, lc, lane, nullptr);
 }
+#endif  // AKO_MEASURE
 
 }  // namespace ako

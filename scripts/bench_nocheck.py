@@ -6,7 +6,7 @@ from ako_amd import api
 from oracle import pyoracle as po
 w = h = int(os.environ.get("W", "8192"))
 img = po.gen_image(0, w, h)
-s = api.settings(wavelet=0, compression=2, q=16, g=16)
+s = api.settings(wavelet=int(os.environ.get("WAVELET", "0")), compression=2, q=int(os.environ.get("Q", "16")), g=int(os.environ.get("G", "16")))
 with api.Plan(s, 4, w, h) as plan:
     d = torch.from_numpy(img).cuda().reshape(1, h, w, 4)
     st = plan.new_streams(); back = plan.new_images()

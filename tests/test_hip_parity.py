@@ -43,13 +43,13 @@ def hip_decode_body(body, s, ch, w, h):
 
 
 @pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt",
-                        "stream-tail1", "stream-tail2", "stream-nostaged", "auto-fuse", "stream-fuse"])
+                        "stream-tail1", "stream-tail2", "stream-nostaged", "auto-fuse", "stream-fuse", "auto-nofuse2", "stream-nofuse2"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
     kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
     switches the fused in-LDS tail kernel off (AKO_HIP_TAIL=0) so every level runs as its own launch;
     '-noopt' runs the exact int16-wrapping inverse alone instead of optimistic fp32 + exact fallback."""
-    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE")}
+    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE", "AKO_HIP_FUSE2")}
     mode = request.param
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
     # AKO_HIP_TAIL: 0 no fused tail, 1 window-engine tail, 2 segment-engine tail, unset = chosen per launch
@@ -65,7 +65,10 @@ def path_mode(request):
     # u8 -> planar int16 staging in front of the int16 streaming kernels
     os.environ["AKO_HIP_STAGED"] = "0" if mode.endswith("nostaged") else "1"
     # '-fuse': forward levels 0 and 1 of eligible RGBA plans in one strip walk (k_forward_fused_u8; off by default)
-    os.environ["AKO_HIP_FUSE"] = "1" if mode.endswith("fuse") else "0"
+    os.environ["AKO_HIP_FUSE"] = "1" if mode.endswith("-fuse") else "0"
+    # '-nofuse2' and '-fuse': levels 0 and 1 as launches of their own (the two-level workgroup kernels of ako_fused.hip.h,
+    # which eligible RGBA plans take by default, switched off)
+    os.environ["AKO_HIP_FUSE2"] = "0" if (mode.endswith("-nofuse2") or mode.endswith("-fuse")) else "3"
     yield mode
     for k, v in old.items():
         if v is None:
@@ -327,6 +330,77 @@ def test_fused_levels_0_and_1_forward(po):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def _with_env(env):
+    """context manager: os.environ entries set for the block, restored afterwards"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: os.environ.get(k) for k in env}
+        try:
+            for k, v in env.items():
+                os.environ[k] = str(v)
+            yield
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return cm()
+
+
+def test_fused2_levels_0_and_1_in_one_workgroup_walk(po):
+    """AKO_HIP_FUSE2 (default 3): levels 0 and 1 of an eligible RGBA plan in ONE launch per direction, the level-0
+    low-pass plane handed from wave to wave through LDS (ako_fused.hip.h).  Shapes around every way its workgroups
+    (six strips, 704 / 712 net level-0 columns forward / inverse), its level-1 strips, its row segments (multiples of
+    6 rows, short first / last segment) and the four borders can fall; DD13/7 and CDF5/3; CLAMP, MIRROR, ZERO; tiled
+    and batched; gates and quantizers -- streams byte-for-byte against the oracle, decoded pixels bit-exact, and the
+    kernel records must show that the fused kernels are what ran."""
+    nrng = np.random.default_rng(5150)
+    cases = [(1024, 96, 0), (1408, 200, 0), (1424, 264, 0), (2816, 120, 0), (2832, 48, 0), (4096, 192, 0), (1040, 776, 0),
+             (1440, 1000, 0), (2048, 1024, 512), (1536, 768, 256), (8192, 104, 0), (5648, 72, 0), (64, 64, 0), (136, 52, 0)]
+    knobs = [{}, {"AKO_HIP_F2_ROWS": 24}, {"AKO_HIP_F2_ROWS": 48, "AKO_HIP_F2_EDGE": 0}, {"AKO_HIP_F2_ROWS": 36, "AKO_HIP_F2_EDGE": 30}]
+    for path in ("auto", "stream"):
+        for ci, (w, h, tiles) in enumerate(cases):
+            for wavelet in (0, 1):
+                env = dict(knobs[(ci + wavelet) % len(knobs)], AKO_HIP_PATH=path, AKO_HIP_FUSE2=3)
+                wrap = int(nrng.choice([0, 1, 3]))
+                q = int(nrng.choice([0, 1, 7, 16, 40]))
+                g = int(nrng.choice([0, 0, 5, 16]))
+                batch = 2 if (w * h <= 1024 * 200 and ci % 2 == 0) else 1
+                imgs = [(po.gen_image(0, w, h, int(nrng.integers(1, 1 << 30))) if nrng.random() < 0.5
+                         else nrng.integers(0, 256, (h, w, 4), dtype=np.uint8)) for _ in range(batch)]
+                s = po.settings(wavelet=wavelet, wrap=wrap, color=0, compression=2, q=q, g=g, tiles=tiles)
+                blobs = []
+                for img in imgs:
+                    ob, st = po.encode_image(s, img)
+                    assert st == 0
+                    blobs.append(ob)
+                s.color = po.effective_color(s)
+                with _with_env(env):
+                    with api.Plan(_to_api(s), 4, w, h, batch=batch) as plan:
+                        plan.set_profiling(True)
+                        d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).cuda())
+                        d_back = plan.decode(d_streams)
+                        plan.synchronize()
+                        enc_names = [r["name"] for r in plan.kernel_records(False)]
+                        dec_names = [r["name"] for r in plan.kernel_records(True)]
+                        bodies = d_streams.cpu().numpy().reshape(batch, -1).view(np.uint8)
+                        back = d_back.cpu().numpy().reshape(batch, h, w, 4)
+                tag = (path, w, h, tiles, wavelet, wrap, q, g, env)
+                tile_w = tiles or w
+                # 'auto' takes tiles of 512 level-0 columns and more; 'stream' everything whose level 1 is a launch of its
+                # own (tiles of 256 pixels and less have it in the tail kernel)
+                if tile_w >= 1024 or (path == "stream" and tile_w >= 512):
+                    assert enc_names[0].startswith("fwd_fused2_"), (tag, enc_names[:3])
+                    assert any(n.startswith("inv_fused2_") for n in dec_names), (tag, dec_names[-4:])
+                for k in range(batch):
+                    assert np.array_equal(bodies[k], blobs[k][16:]), (tag, k)
+                    od, _, _ = po.decode_image(blobs[k])
+                    assert np.array_equal(back[k], od), (tag, k)
 
 
 def test_workgroup_shapes_and_lockstep_knobs(po):
