@@ -326,9 +326,16 @@ def decode(blob, events=None):
     # the library's buffer IS the result (no copy: for a large image that copy costs more than the decode); it is
     # released through akoDefaultFree when the array -- and every view of it -- is gone
     n = h.value * w.value * ch.value
-    img = np.frombuffer((C.c_uint8 * n).from_address(p), dtype=np.uint8).reshape(h.value, w.value, ch.value).view(_Owned)
-    img._release = weakref.finalize(img, lib().akoDefaultFree, C.c_void_p(p))
-    return img, s
+    return _owned_array(p, n, np.uint8, (h.value, w.value, ch.value), lib().akoDefaultFree), s
+
+
+def _owned_array(p: int, nbytes: int, dtype, shape, free) -> np.ndarray:
+    """ndarray over `nbytes` at address `p` that the library allocated.  The finalizer hangs on the ctypes buffer at the
+    ROOT of every view chain (NumPy collapses the .base of a plain view -- np.asarray(a), a.view(np.ndarray), a slice --
+    to that buffer, not to the array it was taken from), so the memory lives exactly as long as any array over it."""
+    root = (C.c_uint8 * nbytes).from_address(p)
+    weakref.finalize(root, free, C.c_void_p(p))
+    return np.frombuffer(root, dtype=dtype).reshape(shape).view(_Owned)
 
 
 def pinned_empty(shape, dtype=np.uint8):
@@ -339,13 +346,11 @@ def pinned_empty(shape, dtype=np.uint8):
     p = lib().akoHipHostAlloc(max(n, 1))
     if not p:
         raise MemoryError(f"akoHipHostAlloc({n})")
-    a = np.frombuffer((C.c_uint8 * n).from_address(p), dtype=dt).reshape(shape).view(_Owned)
-    a._release = weakref.finalize(a, lib().akoHipHostFree, C.c_void_p(p))
-    return a
+    return _owned_array(p, n, dt, shape, lib().akoHipHostFree)
 
 
 class _Owned(np.ndarray):
-    """An ndarray over memory the library allocated; freed when the array is collected."""
+    """An ndarray over memory the library allocated (see _owned_array for when it is freed)."""
 
 
 # ---------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ from __future__ import annotations
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -56,11 +57,16 @@ def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
                    os.environ.get("AKO_HIPCC_EXTRA", "").split() +  # experiments only
                    ["-c", os.path.join(CSRC, src), "-o", o])
             print(" ".join(cmd), flush=True)
-            jobs.append((cmd, subprocess.Popen(cmd)))
+            jobs.append((cmd, subprocess.Popen(cmd), o, time.time()))
         objs.append(o)
-    for cmd, job in jobs:
+    failed = None
+    for cmd, job, o, t0 in jobs:
         if job.wait() != 0:
-            raise subprocess.CalledProcessError(job.returncode, cmd)
+            failed = failed or subprocess.CalledProcessError(job.returncode, cmd)
+        else:
+            os.utime(o, (t0, t0))  # dated by the START of its build: a source edited while it compiled is newer
+    if failed:
+        raise failed
     c_deps = [os.path.join(CSRC, h) for h in C_HEADERS]
     for src in C_SOURCES:
         o = os.path.join(OBJ, os.path.basename(src) + ".o")

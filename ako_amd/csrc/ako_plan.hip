@@ -139,10 +139,9 @@ struct Tuning
 	int lockstep = 3;      // AKO_HIP_LOCKSTEP: StreamGeom::lockstep (bit 0 barrier every six slots, bit 1 strip-major units)
 	int fwd_pairs = 2;     // AKO_HIP_FWD_PAIRS: pairs of waves (= neighbouring strips) per workgroup of the u8 forward kernel
 	int inv_pairs = 2;     // AKO_HIP_INV_PAIRS: same for the u8 inverse kernel (1, 2 or 4)
-	bool fuse = false;     // AKO_HIP_FUSE=1: forward level 1 inside the level-0 strip walk (k_forward_fused_u8) instead of a launch of
-	                       // its own.  Bit-exact and parity-tested, but off by default: measured slower
-	int fuse2 = 3;         // AKO_HIP_FUSE2: levels 0 and 1 of eligible RGBA plans in one workgroup walk, the level-0 low-pass plane
-	                       // handed over through LDS (ako_fused.hip.h): bit 0 forward, bit 1 inverse
+	int fuse2 = 0;         // AKO_HIP_FUSE2: levels 0 and 1 of eligible RGBA plans in one workgroup walk, the level-0 low-pass plane
+	                       // handed over through LDS (ako_fused.hip.h): bit 0 forward, bit 1 inverse.  Bit-exact and parity-tested,
+	                       // off by default: measured slower than the level-per-kernel launches
 	int f2_rows = 0;       // AKO_HIP_F2_ROWS: rows per segment of those kernels (0 = one round of workgroups)
 	int f2_edge = -1;      // AKO_HIP_F2_EDGE: rows of their first / last segment (-1 = chosen, 0 = like the others)
 	uint32_t dbg = 0;      // AKO_HIP_DBG bits (kernel side experiments)
@@ -181,8 +180,7 @@ struct Tuning
 			t.fwd_pairs = 2;
 		if (t.inv_pairs != 1 && t.inv_pairs != 4)
 			t.inv_pairs = 2;
-		t.fuse = num("AKO_HIP_FUSE", 0) != 0;
-		t.fuse2 = num("AKO_HIP_FUSE2", 3) & 3;
+		t.fuse2 = num("AKO_HIP_FUSE2", 0) & 3;
 		t.f2_rows = num("AKO_HIP_F2_ROWS", 0);
 		t.f2_edge = num("AKO_HIP_F2_EDGE", -1);
 #ifdef AKO_MEASURE  // measurement builds only: the shipped library does not read AKO_HIP_DBG
@@ -506,48 +504,6 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		G.edge_rows = EDGE_ROWS;
 		G.segs = 3 + (L.th - 3 * EDGE_ROWS + seg_rows - 1) / seg_rows;
 	}
-	return G;
-}
-
-// Forward levels 0 and 1 of a u8 RGBA plan in ONE strip walk (k_forward_fused_u8): shapes without phantom columns or
-// rows at either level, CLAMP or ZERO borders (the level-1 row pass of the fused kernel implements those two), the
-// same wavelet at both levels, and a level 1 that is not the last one (its low-pass goes to the scratch plane).
-bool fuse_eligible(const akoHipPlan* pl, const Group& g, bool u8_level0)
-{
-	if (!pl->tune.fuse || !u8_level0 || pl->channels != 4 || g.levels.size() < 3)
-		return false;
-	const LevelGeom &L0 = g.levels[0], &L1 = g.levels[1];
-	if (pl->s.wrap != AKO_WRAP_CLAMP && pl->s.wrap != AKO_WRAP_ZERO)
-		return false;
-	if ((L0.cw % 8) != 0 || (L0.ch % 4) != 0 || L0.kind != L1.kind)
-		return false;
-	if (!stream_eligible(pl, L0, true) || !stream_eligible(pl, L1, false))
-		return false;
-	const uint32_t min_cols = (path_mode(pl) == PATH_STREAM) ? 64 : 256;  // below that a fused strip is mostly halo
-	return L0.tw >= min_cols && L0.th >= 96;
-}
-
-StreamGeom fused_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit)
-{
-	StreamGeom G;
-	G.strips = (L.tw + FNET - 1) / FNET;
-	G.wide = 0;
-	G.lockstep = (uint32_t)pl->tune.lockstep;
-	// the fused walk re-computes 18 row slots per segment: longer segments than the plain level-0 kernel's, two
-	// rounds of 3 waves per SIMD; rows per segment a multiple of 6 (the walk starts on a slot = 3 mod 6), the border
-	// segments 24 rows (the first one and the last one run the spilling border bodies)
-	const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
-	uint64_t segs = (uint64_t)(pl->tune.u8_waves > 0 ? pl->tune.u8_waves : 6144) / per_seg;
-	if (segs < 1)
-		segs = 1;
-	uint32_t seg_rows = (uint32_t)((L.th + segs - 1) / segs);
-	seg_rows = ((seg_rows + 5) / 6) * 6;
-	if (seg_rows < 48)
-		seg_rows = 48;
-	constexpr uint32_t EDGE = 24;
-	G.seg_rows = seg_rows;
-	G.edge_rows = EDGE;
-	G.segs = 3 + (L.th - 3 * EDGE + seg_rows - 1) / seg_rows;
 	return G;
 }
 
@@ -971,50 +927,6 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				l = 1;  // level 1 is done
 				continue;
 			}
-			if (l == 0 && lt >= 2 && fuse_eligible(pl, g, u8))
-			{
-				// levels 0 and 1 in one strip walk: level 0's low-pass plane is never written
-				const LevelGeom& L1 = g.levels[1];
-				LevelParams P1;
-				fill_common(P1, pl, g, L1);
-				P1.stream = (int16_t*)d_streams;
-				P.img = (uint8_t*)d_images;
-				P.planes_per_wg = 2, P.plane_groups = 2;
-				P1.planes_per_wg = 2, P1.plane_groups = 2;
-				if (nl == 2)
-					P1.ll_out_stream = 1;
-				else
-				{
-					P1.dst = pl->scratch[1];
-					P1.dst_pitch = L1.tw;
-					P1.dst_plane_stride = scratch_plane_elems(g, 1);
-					P1.dst_inst_stride = P1.dst_plane_stride * pl->channels;
-				}
-				const StreamGeom G = fused_geometry(pl, L, (uint64_t)P.plane_groups * insts);
-				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
-				const uint64_t blocks = (units + (THREADS / 64) - 1) / (THREADS / 64);
-				if (int rc = check_blocks(blocks))
-					return rc;
-				Launch LF{pl, 0};
-				if (int rc = LF.begin())
-					return rc;
-				if (L.kind == K_DD137)
-					hipLaunchKernelGGL((k_forward_fused_u8<K_DD137>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, P1, G);
-				else if (L.kind == K_CDF53)
-					hipLaunchKernelGGL((k_forward_fused_u8<K_CDF53>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, P1, G);
-				else
-					hipLaunchKernelGGL((k_forward_fused_u8<K_HAAR>), dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, P1, G);
-				char fname[48];
-				snprintf(fname, sizeof fname, "fwd_fused01_%s_u8", kind_name(L.kind));
-				const uint64_t smp0 = (uint64_t)L.cw * L.ch * pl->channels * insts;
-				// algorithmic bytes of the two levels together: pixels in; C / B / D of level 0, everything of level 1 out
-				const uint64_t out0 = ((uint64_t)3 * L.tw * L.th + 1) * pl->channels * insts;
-				const uint64_t out1 = ((uint64_t)4 * L1.tw * L1.th + 1) * pl->channels * insts;
-				if (int rc = LF.end(fname, 0, (uint32_t)gi, smp0, smp0, (out0 + out1) * 2))
-					return rc;
-				l = 1;  // level 1 is done
-				continue;
-			}
 			if (u8)
 			{
 				P.img = (uint8_t*)d_images;
@@ -1348,7 +1260,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.fuse, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;
@@ -2075,7 +1987,7 @@ static int requantize(akoHipPlan* pl, int quantization, int gate, const void* d_
 		s.start = start, s.count = count, s.q = q, s.g = g;
 		s.rq = (float)((1.0 / (double)(q < 1 ? 1 : q)) * (1.0 + 1e-6));
 		s.first_block = blocks;
-		blocks += (uint32_t)((count + RQ_CHUNK - 1) / RQ_CHUNK);
+		blocks += (uint32_t)((count + 7 + RQ_CHUNK - 1) / RQ_CHUNK);  // + 7: the kernel's windows are 16-byte aligned in the buffer
 		segs.push_back(s);
 	};
 	for (const TileInfo& ti : pl->tiles)

@@ -27,6 +27,10 @@ struct RqSegment  // one [head C B D] group of one tile, level and plane; or a r
 	uint32_t first_block;
 };
 
+// A thread owns one 16-byte ALIGNED window of eight values (aligned in the stream buffer, whatever the segment's first
+// index is): windows that lie inside the segment are one 16-byte load and one 16-byte store with the values re-quantized
+// in registers; the window a segment starts or ends in is shared with its neighbour and goes value by value.  The host
+// sizes a segment's blocks for the worst alignment (count + 7 values).
 __global__ __launch_bounds__(RQ_THREADS) void k_requantize(const int16_t* __restrict__ in, int16_t* __restrict__ out,
                                                           const RqSegment* __restrict__ segs, uint32_t n_segs,
                                                           uint64_t image_stride, uint32_t blocks_per_image)
@@ -43,20 +47,37 @@ __global__ __launch_bounds__(RQ_THREADS) void k_requantize(const int16_t* __rest
 			hi = mid - 1;
 	}
 	const RqSegment s = segs[lo];
-	const uint64_t base = (uint64_t)image * image_stride + s.start;
-	const uint64_t off0 = (uint64_t)(blk - s.first_block) * RQ_CHUNK + (uint64_t)threadIdx.x * RQ_PER_THREAD;
-	const int16_t* src = in + base;
-	int16_t* dst = out + base;
+	const uint64_t seg_lo = (uint64_t)image * image_stride + s.start, seg_hi = seg_lo + s.count;  // absolute value indices
+	const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+	const uint64_t w0 = (aligned ? (seg_lo & ~7ull) : seg_lo) + (uint64_t)(blk - s.first_block) * RQ_CHUNK + (uint64_t)threadIdx.x * RQ_PER_THREAD;
+	if (w0 >= seg_hi)
+		return;
+	auto requant = [&](int v, bool head) {
+		if (s.q == 0)
+			return v;  // low-pass section: copied
+		return head ? s.q : quantize(v, s.q, s.g, s.rq);  // the head holds the q in use (lifting.c:266-267)
+	};
+	if (aligned && w0 >= seg_lo && w0 + RQ_PER_THREAD <= seg_hi)
+	{
+		const uint4 raw = *reinterpret_cast<const uint4*>(in + w0);
+		const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+		uint32_t r[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			const int a = requant((int)(int16_t)(w[k] & 0xFFFFu), k == 0 && w0 == seg_lo);
+			const int b = requant((int)w[k] >> 16, false);
+			r[k] = ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
+		}
+		*reinterpret_cast<uint4*>(out + w0) = make_uint4(r[0], r[1], r[2], r[3]);
+		return;
+	}
 #pragma unroll
 	for (int k = 0; k < RQ_PER_THREAD; k++)
 	{
-		const uint64_t i = off0 + k;
-		if (i >= s.count)
-			break;
-		int v = src[i];
-		if (s.q != 0)
-			v = (i == 0) ? s.q : quantize(v, s.q, s.g, s.rq);  // the head holds the q in use (lifting.c:266-267)
-		dst[i] = (int16_t)v;
+		const uint64_t i = w0 + k;
+		if (i >= seg_lo && i < seg_hi)
+			out[i] = (int16_t)requant(in[i], i == seg_lo);
 	}
 }
 

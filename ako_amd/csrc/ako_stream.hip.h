@@ -641,18 +641,8 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	return lc;
 }
 
-// ---- level 1 fused into the level-0 strip walk (forward) -----------------------------------------
-// A lane's two low-pass columns of a level-0 row are the even and the odd sample of ONE level-1 column, so the wave
-// that walks a strip at level 0 can lift the strip's low-pass rows once more on the spot instead of writing them to
-// HBM for the next launch to read back (134 MB each way for an 8192x8192 RGBA image).  Level-1 neighbours sit one
-// and two lanes away; the level-1 column pipeline is fed every second row slot.  The price is halo: level-1 outputs
-// are valid in lanes 5..58 only (three more lanes of halo on either side than level 0 needs), so a fused strip nets
-// 108 level-0 columns instead of 120, and a segment walks 12 more row slots.
-constexpr int FNET = 108;  // net level-0 coefficient columns of a fused strip (54 level-1 columns)
-constexpr int FORG = 10;   // lane 0 holds level-0 columns strip * FNET - FORG, +1
-constexpr int FNET_LO = FORG / 2, FNET_HI = FNET_LO + FNET / 2;  // lanes 5 .. 58 store
-
-// lane_columns() for an arbitrary first column and net lane range (even Tc, no phantom column: the fused path's shapes)
+// ---- helpers of the two-level workgroup kernels (ako_fused.hip.h) ----
+// lane_columns() for an arbitrary first column and net lane range (even Tc, no phantom column)
 __device__ __forceinline__ LaneCols lane_columns_at(int c_base, int net_lo, int net_hi, int lane, int Tc, int wrap)
 {
 	LaneCols lc;
@@ -678,77 +668,8 @@ __device__ __forceinline__ LaneCols lane_columns_at(int c_base, int net_lo, int 
 	lc.xs = 2 * lc.cs;
 	return lc;
 }
-__host__ __device__ __forceinline__ bool fused_strip_needs_border_code(uint32_t strip, int Tc, int wrap)
-{
-	const int c_base = (int)strip * FNET - FORG;
-	return (wrap != W_REPEAT) && (c_base < 0 || c_base + 128 > Tc);
-}
-
-// what a lane knows about its ONE level-1 column
-struct Lane1
-{
-	int c;              // level-1 column of this lane
-	bool left, right;   // the strip holds out-of-range lanes on that side
-	bool oob_l, oob_r;  // this lane is one
-	int lane_first, lane_last;
-	bool net;           // this lane stores its column
-};
-__device__ __forceinline__ Lane1 lane1_of(int c_base0, int lane, int Tc1)
-{
-	Lane1 l;
-	const int c_base = c_base0 / 2;  // c_base0 is even
-	l.c = c_base + lane;
-	l.left = c_base < 0, l.right = c_base + 64 > Tc1;
-	l.oob_l = l.c < 0, l.oob_r = l.c >= Tc1;
-	l.lane_first = l.left ? -c_base : 0, l.lane_last = Tc1 - 1 - c_base;
-	l.net = (lane >= FNET_LO) && (lane < FNET_HI) && !l.oob_l && !l.oob_r;
-	return l;
-}
-
-// Horizontal forward lift of a level-1 row held one column per lane: even sample E, odd sample O -> low-pass L,
-// high-pass H of that column.  CLAMP and ZERO borders: out-of-range lanes take the nearest in-range
-// value / zero before each round of neighbour shifts, which is what the table prescribes for every tap of these two
-// modes.  Valid in lanes 3 .. 60.
-template <int KIND, bool HEDGE>
-__device__ __forceinline__ void hlift1_forward(float E, float O, const Lane1& ed, int wrap, float& L, float& H)
-{
-	if constexpr (KIND == K_HAAR)
-	{
-		L = E, H = O - E;
-		return;
-	}
-	auto fix = [&](float& a) {
-		if (ed.left)
-		{
-			const float f = (wrap == W_ZERO) ? 0.0f : read_lane(a, ed.lane_first);
-			if (ed.oob_l)
-				a = f;
-		}
-		if (ed.right)
-		{
-			const float f = (wrap == W_ZERO) ? 0.0f : read_lane(a, ed.lane_last);
-			if (ed.oob_r)
-				a = f;
-		}
-	};
-	if (HEDGE)
-		fix(E);
-	const float eR1 = from_next_lane(E);
-	float eL = 0.0f, eR2 = 0.0f;
-	if (KIND == K_DD137)
-		eL = from_prev_lane(E), eR2 = from_next_lane(eR1);
-	H = lift_add<false>(O, sum_p<KIND, +1>(eL, E, eR1, eR2), shift_p<KIND>());
-	if (HEDGE)
-		fix(H);
-	const float hL1 = from_prev_lane(H);
-	float hL2 = 0.0f, hR1 = 0.0f;
-	if (KIND == K_DD137)
-		hL2 = from_prev_lane(hL1), hR1 = from_next_lane(H);
-	L = lift_add<false>(E, sum_u<KIND, +1>(hL2, hL1, H, hR1), shift_u<KIND>());
-}
-
 // vstep_forward() with a ring of THREE for the odd samples as well, so that every ring index has period 3: the level-1
-// pipeline of the fused kernel advances every second row slot, three times per trip of the 6-slot unrolled loop.
+// pipeline of the two-level kernels advances every second row slot, three times per trip of the 6-slot unrolled loop.
 template <typename V>
 struct VFwd3
 {
@@ -1065,14 +986,11 @@ struct FwdRaw<false>
 // chain: with the running prefetch every slot of such a wave waits for its own round trip to memory, with all
 // loads in flight at once the segment costs one round trip.  (A single pass over exactly N slots: the ring indices
 // of the column pipeline stay compile-time constants for any N.)
-// FUSE: level 1 is lifted in the same strip walk (u8 float pipeline only; P1 = the level-1 parameters): the
-// level-0 low-pass rows never leave the wave, see "level 1 fused into the level-0 strip walk" above.
 template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE, int DEEP, bool CFAST = false, int PF = 2, int LATE = 0,
-          bool MEMONLY = false, bool FUSE = false>
+          bool MEMONLY = false>
 __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
-                                                    const LaneCols& lc, int lane, const LevelParams* P1 = nullptr)
+                                                    const LaneCols& lc, int lane)
 {
-	static_assert(!FUSE || (U8 && NPL == 2 && !NARROW && DEEP == 0 && LATE > 0 && !MEMONLY), "fused form: u8 pairs on the float pipe");
 	const TileDesc td = P.tiles[id.tile];
 	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
@@ -1151,39 +1069,6 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 
 	const float gf_luma = (float)P.g_luma, gf_chroma = (float)P.g_chroma;
 
-	// ---- fused level 1: geometry, destinations, pipeline state ----
-	const int T1c = FUSE ? (int)P1->sub_w : 0, T1r = FUSE ? (int)P1->sub_h : 0;
-	const Lane1 l1 = FUSE ? lane1_of(c0 - 2 * lane, lane, T1c) : Lane1{};
-	const uint32_t lane1_off = (FUSE && l1.net) ? (uint32_t)(l1.c * 2) : OOB;
-	const int r1_lo = r_lo / 2, r1_hi = r_hi / 2;  // level-1 rows this segment stores (r_lo, r_hi are even when fused)
-	const uint32_t nsub1_b = FUSE ? (uint32_t)((uint64_t)T1c * T1r * 2) : 0;
-	__amdgpu_buffer_rsrc_t rs_ll1 = rs_ll;
-	uint32_t ll1_pitch = 0, ll1_off[NPL] = {}, grp1_off[NPL] = {};
-	float gf1[NPL] = {}, rq1[NPL] = {};
-	VFwd3<float> st1[NPL][2];
-	float keepL[NPL] = {}, keepH[NPL] = {}, holdEL[NPL] = {}, holdEH[NPL] = {}, holdOL[NPL] = {}, holdOH[NPL] = {};
-	if constexpr (FUSE)
-	{
-		int16_t* root1 = P1->ll_out_stream ? tile_stream : (P1->dst + inst * P1->dst_inst_stride);
-		const uint64_t left1 = P1->ll_out_stream ? stream_left : (uint64_t)P1->channels * P1->dst_plane_stride * 2;
-		rs_ll1 = __builtin_amdgcn_make_buffer_rsrc(root1, 0, (int)(uint32_t)(left1 < 0xFFFFFFFFull ? left1 : 0xFFFFFFFFull), RSRC_FLAGS);
-		ll1_pitch = P1->ll_out_stream ? (uint32_t)T1c : P1->dst_pitch;
-#pragma unroll
-		for (int p = 0; p < NPL; p++)
-		{
-			const int pl = p_first + p * P_STEP;
-			grp1_off[p] = (uint32_t)((P1->grp_off[pl] + 1) * 2);
-			ll1_off[p] = (uint32_t)((P1->ll_out_stream ? P1->lp_off[pl] : (uint64_t)pl * P1->dst_plane_stride) * 2);
-			gf1[p] = (float)((pl == 0) ? P1->g_luma : P1->g_chroma);
-			rq1[p] = (pl == 0) ? P1->rq_luma : P1->rq_chroma;
-			st1[p][0] = st1[p][1] = VFwd3<float>{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-			if (id.strip == 0 && id.seg == 0 && lane == 0)
-				tile_stream[P1->grp_off[pl]] = (int16_t)((pl == 0) ? P1->q_luma : P1->q_chroma);
-		}
-	}
-	(void)T1r, (void)lane1_off, (void)r1_lo, (void)r1_hi, (void)nsub1_b, (void)ll1_pitch, (void)keepL, (void)keepH;
-	(void)holdEL, (void)holdEH, (void)holdOL, (void)holdOH, (void)gf1, (void)rq1, (void)st1, (void)rs_ll1;
-
 	// narrowing kernels compute on the integer pipe, the others (narrowing provably a no-op) on fp32
 	using V = std::conditional_t<NARROW, int, float>;
 	VFwd<V> st[NPL][4];
@@ -1214,16 +1099,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		}
 	};
 
-	// Row slots walked.  Fused: level 1 needs the low-pass rows r_lo - 6 .. r_hi + 5, i.e. slots r_lo - 9 .. r_hi + 8,
-	// and the walk starts on a slot = 3 (mod 6) so that row r = v - 3 has the parity of the unroll position K and
-	// level-1 slot (r - 1) / 2 the ring position (K - 1) / 2.
-	int v_begin = r_lo - 3, n_slots = r_hi + 3 - v_begin;
-	if constexpr (FUSE)
-	{
-		v_begin = r_lo - 9;
-		v_begin -= (((v_begin - 3) % 6) + 6) % 6;
-		n_slots = r_hi + 9 - v_begin;
-	}
+	const int v_begin = r_lo - 3, n_slots = r_hi + 3 - v_begin;
 	// The two slots fetched ahead of the loop are followed by as many (dropped) stores as a slot issues,
 	// so that the memory operations in flight look the same on entry as on every later trip.
 	auto phantom_stores = [&]() {
@@ -1332,66 +1208,6 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				const float rq = (p_first + p * P_STEP == 0) ? P.rq_luma : P.rq_chroma;
 				pack_row_f(lp, hp, gf, rq, w_ll[p], w_c[p], w_b[p], w_d[p]);
 
-				if constexpr (FUSE)
-				{
-					// the low-pass row r of this plane, one level-1 column per lane: row pass now, column pass with its partner row
-					float Lr, Hr;
-					hlift1_forward<KIND, HEDGE>(lp[0], lp[1], l1, wrap, Lr, Hr);
-					if constexpr ((K & 1) == 0)
-						keepL[p] = Lr, keepH[p] = Hr;  // even row: waits for the odd one
-					else
-					{
-						constexpr int K1 = (K - 1) / 2;
-						const int v1 = (r - 1) / 2;  // level-1 row slot (r is odd here, r - 1 even: exact for negatives too)
-						float eL = keepL[p], eH = keepH[p], oL = Lr, oH = Hr;
-						bool feed = true;
-						if (VEDGE)
-						{
-							// rows beyond the top / bottom border are fed as the unfused kernel's fetch would map them:
-							// nearest pair (CLAMP, and MIRROR's nearest rule) or zeros (ZERO); the slots above the top
-							// border are fed in one burst when rows 0 and 1 exist
-							const bool zero = (wrap == W_ZERO);
-							if (v1 < 0)
-								feed = false;
-							else
-							{
-								if (v1 == 0)
-								{
-									float x0, x1;
-									static_for<3>([&](auto jc) {
-										constexpr int J = decltype(jc)::value;
-										vstep_forward3<KIND, true, J, float>(st1[p][0], zero ? 0.0f : eL, zero ? 0.0f : oL, J - 3, wrap, T1r, x0, x1);
-										vstep_forward3<KIND, true, J, float>(st1[p][1], zero ? 0.0f : eH, zero ? 0.0f : oH, J - 3, wrap, T1r, x0, x1);
-									});
-								}
-								if (v1 == T1r - 1)
-									holdEL[p] = eL, holdEH[p] = eH, holdOL[p] = oL, holdOH[p] = oH;
-								if (v1 >= T1r)
-								{
-									eL = zero ? 0.0f : holdEL[p], eH = zero ? 0.0f : holdEH[p];
-									oL = zero ? 0.0f : holdOL[p], oH = zero ? 0.0f : holdOH[p];
-								}
-							}
-						}
-						if (feed)
-						{
-							float ll1v, c1v, b1v, d1v;
-							vstep_forward3<KIND, VEDGE, K1, float>(st1[p][0], eL, oL, v1, wrap, T1r, ll1v, c1v);
-							vstep_forward3<KIND, VEDGE, K1, float>(st1[p][1], eH, oH, v1, wrap, T1r, b1v, d1v);
-							const int r1 = v1 - 3;
-							const bool ok1 = (r1 >= r1_lo) && (r1 < r1_hi);  // wave-uniform
-							const uint32_t rr1 = (uint32_t)r1;
-							const uint32_t s_ll1 = ok1 ? ll1_off[p] + rr1 * ll1_pitch * 2u : OOB;
-							const uint32_t s_c1 = ok1 ? grp1_off[p] + rr1 * (uint32_t)T1c * 2u : OOB;
-							const uint32_t s_b1 = ok1 ? grp1_off[p] + rr1 * (uint32_t)T1c * 2u + nsub1_b : OOB;
-							const uint32_t s_d1 = ok1 ? grp1_off[p] + rr1 * (uint32_t)T1c * 2u + 2u * nsub1_b : OOB;
-							__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(int)ll1v, rs_ll1, lane1_off, s_ll1, 0);
-							__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(int)gate_scale_f(c1v, gf1[p], rq1[p]), rs_stream, lane1_off, s_c1, 0);
-							__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(int)gate_scale_f(b1v, gf1[p], rq1[p]), rs_stream, lane1_off, s_b1, 0);
-							__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(int)gate_scale_f(d1v, gf1[p], rq1[p]), rs_stream, lane1_off, s_d1, 0);
-						}
-					}
-				}
 			}
 			{
 				const bool row_ok = (r >= r_lo) && (r < r_hi);  // wave-uniform
@@ -1404,8 +1220,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
 					const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
 					const uint32_t s_d = row_ok ? grp_off[p] + row_grp + 2u * nsub_b : OOB;
-					if constexpr (!FUSE)  // (fused: the low-pass row has just been lifted again, it is not stored)
-						__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, lane_off, s_ll, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, lane_off, s_ll, 0);
 					__builtin_amdgcn_raw_buffer_store_b32(w_c[p], rs_stream, lane_off, s_c, AUX_FWD_STREAM_STORE);
 					__builtin_amdgcn_raw_buffer_store_b32(w_b[p], rs_stream, lane_off, s_b, AUX_FWD_STREAM_STORE);
 					__builtin_amdgcn_raw_buffer_store_b32(w_d[p], rs_stream, lane_off, s_d, AUX_FWD_STREAM_STORE);
@@ -1587,50 +1402,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 			AKO_FWD_U8(false, false);
 	}
 #undef AKO_FWD_U8
-}
-
-#ifndef AKO_FUSED_WAVES
-#define AKO_FUSED_WAVES 2
-#endif
-// Levels 0 and 1 of a u8 RGBA plan in one strip walk (forward): P0 / P1 = the parameters of the two levels, G = the
-// fused geometry (strips of FNET net columns).  3 waves per SIMD: the level-1 pipelines cost 36 registers.
-template <int KIND>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(AKO_FUSED_WAVES, AKO_FUSED_WAVES))) void k_forward_fused_u8(const LevelParams P0, const LevelParams P1,
-                                                                                                          const StreamGeom G)
-{
-	const UnitId id = decode_unit(P0, G);
-	if (!id.valid)
-		return;
-	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns_at((int)id.strip * FNET - FORG, FNET_LO, FNET_HI, lane, (int)P0.sub_w, P0.wrap);
-	int r_lo, r_hi, len;
-	segment_rows(G, id.seg, (int)P0.sub_h, r_lo, r_hi, len);
-	// any slot of the fused walk (its 9 + 5 leading, 8 + 5 trailing slots, the prefetch) outside the level?
-	const bool vedge = (r_lo < 18) || (r_lo + len + 18 > (int)P0.sub_h);
-	const bool cfast = (P0.color == C_YCOCG || P0.color == C_YCOCG_Q) && P0.discard == 0;
-#define AKO_FUSED(H, V)                                                                                            \
-	do                                                                                                             \
-	{                                                                                                              \
-		if (cfast)                                                                                                 \
-			forward_stream_body<KIND, 2, true, false, H, V, 0, true, 2, 2, false, true>(P0, G, id, lc, lane, &P1);   \
-		else                                                                                                       \
-			forward_stream_body<KIND, 2, true, false, H, V, 0, false, 2, 2, false, true>(P0, G, id, lc, lane, &P1);  \
-	} while (0)
-	if (__builtin_expect(vedge, 0))
-	{
-		if (lc.hedge)
-			AKO_FUSED(true, true);
-		else
-			AKO_FUSED(false, true);
-	}
-	else
-	{
-		if (lc.hedge)
-			AKO_FUSED(true, false);
-		else
-			AKO_FUSED(false, false);
-	}
-#undef AKO_FUSED
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -69,11 +69,25 @@ def barrier(sync: Callable[[], None] | None = None):
         sync()
 
 
+def max_int(v: int, device=None) -> int:
+    """MAX over ranks of an integer (every rank gets the same number)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(v)
+    t = torch.tensor([int(v)], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None] | None = None,
-                device=None, before_timed: Callable[[], None] | None = None) -> float:
+                device=None, before_timed: Callable[[], None] | None = None, spread: dict | None = None) -> float:
     """W untimed steps, then exactly K steps bracketed by barrier + sync on both sides; returns the MAX
     over ranks of the elapsed seconds (every rank gets the same number).  `before_timed` runs after the
-    warm-up, just before the opening barrier (e.g. to switch per-kernel event recording on)."""
+    warm-up, just before the opening barrier (e.g. to switch per-kernel event recording on).  `spread`, when
+    given, receives the fastest and the slowest rank's time up to its OWN last step (before the closing
+    barrier): {"min_s", "max_s"} -- a straggler shows as a gap between the two."""
     import torch
     import torch.distributed as dist
 
@@ -85,12 +99,25 @@ def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callabl
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    own = None
+    if spread is not None:
+        if sync is not None:
+            sync()
+        own = time.perf_counter() - t0
     barrier(sync)
     elapsed = time.perf_counter() - t0
     if dist.is_available() and dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if own is not None:
+            lo = torch.tensor([own], dtype=torch.float64, device=device if device is not None else "cpu")
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            spread["min_s"], spread["max_s"] = float(lo.item()), float(hi.item())
+    elif own is not None:
+        spread["min_s"] = spread["max_s"] = own
     return elapsed
 
 

@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=4,
                     help="steps in flight: consecutive steps alternate over this many HIP streams / buffer sets")
+    ap.add_argument("--min-region", type=float, default=0.25,
+                    help="shortest timed region in seconds: a region is as many passes of the K steps as it takes (0: exactly K steps)")
     ap.add_argument("--repeats", type=int, default=11,
                     help="timed regions of K steps each; `value` is their median (SURVEY 8d: median of >= 10)")
     return ap.parse_args(argv)
@@ -165,6 +167,18 @@ def cpu_baseline(workload: str):
     from oracle import pyoracle as po
 
     if workload == "lift4096":
+        if po.have_ref():
+            # the reference's own akoLift / akoUnlift (library/lifting.c:171,295) on the FULL workload: one 4096x4096 plane
+            w = h = 4096
+            plane = po.gen_plane(w * h).reshape(h, w)
+            tm = {}
+            st = po.ref_lift_plane(po.DD137, po.CLAMP, plane, tm)
+            back = po.ref_unlift_plane(po.DD137, po.CLAMP, w, h, st, tm)
+            assert np.array_equal(back, plane)
+            dt = tm["lift_s"] + tm["unlift_s"]
+            return {"value": round(w * h / dt / 1e6, 3), "unit": "Mpx/s", "cores": 1, "kind": "reference",
+                    "sample": "one 4096x4096 int16 plane (the whole workload), the reference's akoLift + akoUnlift, DD13/7",
+                    "lift_Mpx_s": round(w * h / tm["lift_s"] / 1e6, 2), "unlift_Mpx_s": round(w * h / tm["unlift_s"] / 1e6, 2)}
         w = h = 2048
         plane = po.gen_plane(w * h).reshape(h, w)
         t0 = time.perf_counter()
@@ -190,9 +204,11 @@ def cpu_baseline(workload: str):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 32))
+    threads = max(1, cores)  # every core of the affinity mask
     if threads > 1:
-        imgs = [po.gen_image(0, w, h, seed=0x9E3779B9 + 1 + k) for k in range(threads)]
+        # one image per thread; beyond 32 threads the images are 2048x2048 (same transform, a quarter of the memory)
+        tw, th_ = (w, h) if threads <= 32 else (2048, 2048)
+        imgs = [po.gen_image(0, tw, th_, seed=0x9E3779B9 + 1 + k) for k in range(threads)]
         res = [None] * threads
 
         def work(k):
@@ -206,24 +222,31 @@ def cpu_baseline(workload: str):
             t.join()
         wall = time.perf_counter() - t0
         slowest = max(r[0] + r[1] for r in res)
-        out["all_cores"] = {"value": round(threads * w * h / slowest / 1e6, 3), "unit": "Mpx/s", "cores": threads,
-                            "nproc": os.cpu_count(), "sample": f"{threads} images of {w}x{h}, one per thread",
-                            "wall_s": round(wall, 2)}
+        out["all_cores"] = {"value": round(threads * tw * th_ / slowest / 1e6, 3), "unit": "Mpx/s", "cores": threads,
+                            "nproc": os.cpu_count(), "sample": f"{threads} images of {tw}x{th_}, one per thread "
+                            "(every core of the affinity mask; the reference itself has no threading)",
+                            "wall_s": round(wall, 2), "by_wall_Mpx_s": round(threads * tw * th_ / wall / 1e6, 1)}
     return out
 
 
 def measured_traffic(workload, kernel, level):
-    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE),
-    collected in separate rocprofv3 --pmc passes by scripts/collect_traffic.sh and stored, corrected as
-    MI355X_MICROARCH.md prescribes, in profiles/traffic.json.  null when no such measurement exists."""
+    """(HBM bytes per launch of the dominant kernel, where that figure comes from).  The bytes are NOT measured by this
+    run: they are looked up in profiles/traffic.json, which scripts/collect_traffic.sh + scripts/make_traffic_json.py
+    fill from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; corrected as MI355X_MICROARCH.md prescribes).
+    (None, reason) when no such measurement exists for this workload / kernel."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, "profiles/traffic.json missing"
     try:
         t = json.load(open(path))
-        return t.get(workload, {}).get(f"{kernel}:{level}", {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+        e = t.get(workload, {}).get(f"{kernel}:{level}")
+        if not e:
+            return None, f"profiles/traffic.json has no entry for {workload} / {kernel}:{level}"
+        src = t.get("_source", {})
+        return e.get("hbm_bytes_per_launch"), ("lookup in profiles/traffic.json (" + src.get("collected", "rocprofv3 --pmc passes") +
+                                               f", commit {src.get('commit', 'unknown')}); not a measurement of this run")
+    except Exception as ex:  # noqa: BLE001
+        return None, f"profiles/traffic.json unreadable: {ex}"
 
 
 def copy_bandwidth(torch, dev):
@@ -363,12 +386,26 @@ def main():
     # path's throughput, not the instrumented one.
     reps = max(1, args.repeats)
     warm = max(args.warmup, nfl)
-    samples = [ad.timed_steps(step, args.steps, warm if i == 0 else 0, sync=torch.cuda.synchronize, device=red_dev)
+    # A region of K steps of this path lasts milliseconds.  When a first region of K steps is shorter than
+    # --min-region seconds, every timed region becomes `mult` back-to-back passes of those K steps (still one barrier +
+    # synchronize on either side, nothing else inside), so that a region is long against timer and launch jitter;
+    # `value` and ms_per_step are per step either way (timing.steps_per_region says how many a region held).
+    probe = ad.timed_steps(step, args.steps, warm, sync=torch.cuda.synchronize, device=red_dev)
+    mult = 1
+    if args.min_region > 0 and probe < args.min_region:
+        mult = int(min(10000, -(-args.min_region // max(probe, 1e-6))))
+    if world > 1:
+        mult = ad.max_int(mult, device=red_dev)  # the same on every rank
+    region_steps = args.steps * mult
+    spreads = [dict() for _ in range(reps)]
+    samples = [ad.timed_steps(step, region_steps, 0, sync=torch.cuda.synchronize, device=red_dev, spread=spreads[i])
                for i in range(reps)]
-    elapsed = statistics.median(samples)
-    samples1 = [ad.timed_steps(step1, args.steps, 1 if i == 0 else 0, sync=torch.cuda.synchronize, device=red_dev)
+    elapsed = statistics.median(samples) / mult
+    med = spreads[sorted(range(reps), key=lambda i: samples[i])[reps // 2]]  # the median region's ranks
+    samples1 = [ad.timed_steps(step1, region_steps, 1 if i == 0 else 0, sync=torch.cuda.synchronize, device=red_dev)
                 for i in range(reps)]
-    elapsed1 = statistics.median(samples1)
+    elapsed1 = statistics.median(samples1) / mult
+    samples = [x / mult for x in samples]  # per K steps, like `elapsed`
 
     # The same K steps once more, untimed, with HIP events around every kernel launch on the kernel's own stream:
     # the per-kernel durations of the overlapped regime (`roofline.timed_region`, the `kernels` table).
@@ -434,6 +471,7 @@ def main():
         kern_ms = sum(a["ms"] for a in agg.values()) / args.steps
         total_alg_bytes = (3 * ch * pixels * 2) if not planes else (8 * pixels)
         copy_gbps = copy_bandwidth(torch, dev)
+        traffic_bytes, traffic_src = measured_traffic(args.workload, dom_key[0], dom_key[1])
         out = {
             "metric": "Mpixels/s encode+decode (DD137, q=16)",
             "value": round(value, 2),
@@ -449,7 +487,10 @@ def main():
             "dtype_note": "int32 arithmetic with int16 narrowing exactly where the reference narrows (int16 storage); "
                           "carried out on the fp32 pipe where every value is provably an exact small integer",
             "data": "synthetic",
-            "timing": {"repeats": reps, "region_s": [round(x, 5) for x in samples], "statistic": "median region of K steps",
+            "timing": {"repeats": reps, "region_s": [round(x * mult, 5) for x in samples], "steps_per_region": region_steps,
+                       "statistic": "median over the regions of (region time / steps_per_region) x K",
+                       "ranks_own_time_s": {"fastest": round(med.get("min_s", 0.0), 5), "slowest": round(med.get("max_s", 0.0), 5),
+                                            "note": "median region: each rank's time to the end of its own last step"},
                        "min_Mpx_s": round(step_px * args.steps / max(samples) / 1e6, 1),
                        "max_Mpx_s": round(step_px * args.steps / min(samples) / 1e6, 1)},
             "value_inflight1": round(value1, 2),
@@ -465,7 +506,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": measured_traffic(args.workload, dom_key[0], dom_key[1]),
+                "traffic": traffic_bytes,
+                "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": dom["bytes"],
                 "measured_copy_GBps": round(copy_gbps, 1),

@@ -275,6 +275,52 @@ def unlift_plane(wavelet: int, wrap: int, w: int, h: int, stream: np.ndarray) ->
     return out
 
 
+def ref_lift_plane(wavelet: int, wrap: int, plane: np.ndarray, timing: dict | None = None) -> np.ndarray:
+    """The compiled reference's private akoLift (library/lifting.c:171; prototype library/ako-private.h:81-82) on ONE
+    int16 plane taken as a one-channel tile, buffers laid out as library/encode.c:84-148 lays them out (plane at the start
+    of work area A, akoPlanesSpacing() values of spacing behind it, stream written to the start of work area B).
+    timing["lift_s"] receives the call's wall time."""
+    import time
+
+    plane = np.ascontiguousarray(plane, dtype=np.int16)
+    h, w = plane.shape
+    R = ref()
+    n = R.akoTileDataSize(w, h) // 2
+    spacing = 2 * w + 2 * h  # akoPlanesSpacing, library/misc.c:104-107
+    a = np.zeros(n + spacing, dtype=np.int16)
+    b = np.zeros(n + spacing, dtype=np.int16)
+    a[: w * h] = plane.reshape(-1)
+    st = settings(wavelet=wavelet, wrap=wrap, color=2, q=0, g=0)
+    R.akoLift.restype = None
+    R.akoLift.argtypes = [C.c_size_t, C.POINTER(Settings), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _i16p, _i16p]
+    t0 = time.perf_counter()
+    R.akoLift(0, C.byref(st), 1, w, h, spacing, _ptr(a, _i16p), _ptr(b, _i16p))
+    if timing is not None:
+        timing["lift_s"] = time.perf_counter() - t0
+    return b[:n].copy()
+
+
+def ref_unlift_plane(wavelet: int, wrap: int, w: int, h: int, stream: np.ndarray, timing: dict | None = None) -> np.ndarray:
+    """The compiled reference's private akoUnlift (library/lifting.c:295) on a one-channel tile stream
+    (call as in library/decode.c:183-187)."""
+    import time
+
+    R = ref()
+    n = R.akoTileDataSize(w, h) // 2
+    spacing = 2 * w + 2 * h
+    a = np.zeros(n + spacing, dtype=np.int16)
+    b = np.zeros(n + spacing, dtype=np.int16)
+    a[:n] = np.ascontiguousarray(stream, dtype=np.int16).reshape(-1)[:n]
+    st = settings(wavelet=wavelet, wrap=wrap, color=2, q=0, g=0)
+    R.akoUnlift.restype = None
+    R.akoUnlift.argtypes = [C.POINTER(Settings), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _i16p, _i16p]
+    t0 = time.perf_counter()
+    R.akoUnlift(C.byref(st), 1, 0, w, h, spacing, _ptr(a, _i16p), _ptr(b, _i16p))
+    if timing is not None:
+        timing["unlift_s"] = time.perf_counter() - t0
+    return b[: w * h].reshape(h, w).copy()
+
+
 def encode_tile(s: Settings, img: np.ndarray) -> np.ndarray:
     """u8 image (h, w, ch) taken as ONE tile -> int16 coefficient stream.  s.color must be effective."""
     img = np.ascontiguousarray(img, dtype=np.uint8)

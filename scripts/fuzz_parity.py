@@ -12,7 +12,7 @@ rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 t_end = time.time() + budget
 done = 0
-knobs = ["AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_LOCKSTEP", "AKO_HIP_FUSE", "AKO_HIP_INV_PAIRS", "AKO_HIP_FWD_PAIRS",
+knobs = ["AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_LOCKSTEP", "AKO_HIP_FUSE2", "AKO_HIP_INV_PAIRS", "AKO_HIP_FWD_PAIRS",
          "AKO_HIP_TAIL_MANY", "AKO_HIP_WIDE", "AKO_HIP_STAGED", "AKO_HIP_DEEP", "AKO_KAGARI_THREADS", "AKO_KAGARI_PAR_MIN"]
 while time.time() < t_end:
     for k in knobs:
@@ -20,7 +20,7 @@ while time.time() < t_end:
     if rng.random() < 0.6:
         os.environ["AKO_HIP_PATH"] = str(rng.choice(["auto", "stream", "generic"]))
         os.environ["AKO_HIP_LOCKSTEP"] = str(rng.integers(0, 4))
-        os.environ["AKO_HIP_FUSE"] = str(rng.integers(0, 2))
+        os.environ["AKO_HIP_FUSE2"] = str(rng.integers(0, 4))
         os.environ["AKO_HIP_INV_PAIRS"] = str(rng.choice([1, 2, 4]))
         os.environ["AKO_HIP_FWD_PAIRS"] = str(rng.choice([1, 2, 4]))
         os.environ["AKO_HIP_TAIL_MANY"] = str(rng.choice([8, 16, 32, 64]))

@@ -506,3 +506,37 @@ def test_forged_heads_are_rejected_before_anything_is_sized_from_them(po):
         with pytest.raises(api.AkoError) as e:
             api.decode(blob)
         assert e.value.status in allowed, (blob[:16].tobytes().hex(), e.value.status)  # 13 no memory, 15 broken input
+
+
+def test_library_owned_arrays_live_as_long_as_any_view():
+    """api.decode() / api.pinned_empty() hand out arrays over memory the library allocated, without a copy.  NumPy
+    collapses the .base of a plain view (np.asarray(a), a.view(np.ndarray), a slice) to the buffer at the root of the
+    chain, so the memory must be freed when THAT goes, not when the first array does (use-after-free)."""
+    import ctypes as C
+    import gc
+
+    from ako_amd import api
+
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    freed = []
+
+    def fake_free(ptr):
+        freed.append(ptr.value)
+        libc.free(ptr)
+
+    p = libc.malloc(4096)
+    a = api._owned_array(p, 4096, np.uint8, (32, 32, 4), fake_free)
+    a[...] = 7
+    plain, sl, vw = np.asarray(a), a[3:5], a.view(np.ndarray)
+    del a
+    gc.collect()
+    assert freed == [] and int(plain.sum()) == 7 * 4096
+    del plain, sl
+    gc.collect()
+    assert freed == []
+    assert int(vw[0, 0, 0]) == 7
+    del vw
+    gc.collect()
+    assert freed == [p]

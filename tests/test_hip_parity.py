@@ -43,13 +43,13 @@ def hip_decode_body(body, s, ch, w, h):
 
 
 @pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt",
-                        "stream-tail1", "stream-tail2", "stream-nostaged", "auto-fuse", "stream-fuse", "auto-nofuse2", "stream-nofuse2"])
+                        "stream-tail1", "stream-tail2", "stream-nostaged", "auto-fuse2", "stream-fuse2"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
     kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
     switches the fused in-LDS tail kernel off (AKO_HIP_TAIL=0) so every level runs as its own launch;
     '-noopt' runs the exact int16-wrapping inverse alone instead of optimistic fp32 + exact fallback."""
-    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE", "AKO_HIP_FUSE2")}
+    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE2")}
     mode = request.param
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
     # AKO_HIP_TAIL: 0 no fused tail, 1 window-engine tail, 2 segment-engine tail, unset = chosen per launch
@@ -64,11 +64,9 @@ def path_mode(request):
     # '-nostaged': u8 images with 1-3 / 5+ channels keep the window engine on level 0 instead of the
     # u8 -> planar int16 staging in front of the int16 streaming kernels
     os.environ["AKO_HIP_STAGED"] = "0" if mode.endswith("nostaged") else "1"
-    # '-fuse': forward levels 0 and 1 of eligible RGBA plans in one strip walk (k_forward_fused_u8; off by default)
-    os.environ["AKO_HIP_FUSE"] = "1" if mode.endswith("-fuse") else "0"
-    # '-nofuse2' and '-fuse': levels 0 and 1 as launches of their own (the two-level workgroup kernels of ako_fused.hip.h,
-    # which eligible RGBA plans take by default, switched off)
-    os.environ["AKO_HIP_FUSE2"] = "0" if (mode.endswith("-nofuse2") or mode.endswith("-fuse")) else "3"
+    # '-fuse2': levels 0 and 1 of eligible RGBA plans in one workgroup walk per direction (the two-level kernels of
+    # ako_fused.hip.h; off by default)
+    os.environ["AKO_HIP_FUSE2"] = "3" if mode.endswith("-fuse2") else "0"
     yield mode
     for k, v in old.items():
         if v is None:
@@ -288,50 +286,6 @@ def test_border_geometries_of_the_streaming_kernels(po, path_mode):
             assert np.array_equal(dec, od), (w, h, ch, wavelet, wrap, q)
 
 
-def test_fused_levels_0_and_1_forward(po):
-    """AKO_HIP_FUSE=1: forward levels 0 and 1 of an RGBA plan in ONE strip walk (k_forward_fused_u8).
-    Shapes around every way its strips (108 net level-0 coefficient columns each), segments (multiples of 6 rows,
-    18-row lead-in) and borders can fall, all three wavelets, both wraps it takes, tiled and not, colours, gates --
-    byte-for-byte against the oracle, and the kernel records must show that the fused kernel is what ran."""
-    nrng = np.random.default_rng(2718)
-    old = {k: os.environ.get(k) for k in ("AKO_HIP_FUSE", "AKO_HIP_PATH")}
-    cases = [(512, 192, 0), (528, 200, 0), (1024, 1024, 0), (2048, 264, 0), (432, 392, 0), (448, 1000, 0),
-             (1744, 208, 0), (1024, 768, 256), (2048, 1024, 512), (4096, 192, 0), (880, 776, 0)]
-    try:
-        os.environ["AKO_HIP_FUSE"] = "1"
-        for path in ("auto", "stream"):
-            os.environ["AKO_HIP_PATH"] = path
-            for (w, h, tiles) in cases:
-                for wavelet in (0, 1, 2):
-                    wrap = int(nrng.choice([0, 3]))
-                    q = int(nrng.choice([0, 1, 7, 16, 40]))
-                    g = int(nrng.choice([0, 0, 5, 16]))
-                    color = int(nrng.choice([0, 1, 2, 3]))
-                    img = (po.gen_image(0, w, h, int(nrng.integers(1, 1 << 30))) if nrng.random() < 0.5
-                           else nrng.integers(0, 256, (h, w, 4), dtype=np.uint8))
-                    s = po.settings(wavelet=wavelet, wrap=wrap, color=color, compression=2, q=q, g=g, tiles=tiles)
-                    ob, st = po.encode_image(s, img)
-                    assert st == 0
-                    s.color = po.effective_color(s)
-                    with api.Plan(_to_api(s), 4, w, h) as plan:
-                        plan.set_profiling(True)
-                        d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(img)[None]).cuda())
-                        plan.synchronize()
-                        names = [r["name"] for r in plan.kernel_records(False)]
-                        body = d_streams.cpu().numpy().reshape(-1).view(np.uint8)
-                    # 'auto' keeps tiles of fewer than 256 level-0 columns on the separate kernels (a fused strip there
-                    # is mostly halo), 'stream' fuses from 64 columns on; 256-pixel tiles have level 1 in the tail kernel
-                    if (tiles or w) >= 512 or (path == "stream" and tiles == 0):
-                        assert names[0].startswith("fwd_fused01_"), (path, w, h, tiles, wavelet, names[:3])
-                    assert np.array_equal(body, ob[16:]), (path, w, h, tiles, wavelet, wrap, q, g, color)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def _with_env(env):
     """context manager: os.environ entries set for the block, restored afterwards"""
     import contextlib
@@ -353,7 +307,7 @@ def _with_env(env):
 
 
 def test_fused2_levels_0_and_1_in_one_workgroup_walk(po):
-    """AKO_HIP_FUSE2 (default 3): levels 0 and 1 of an eligible RGBA plan in ONE launch per direction, the level-0
+    """AKO_HIP_FUSE2=3 (off by default): levels 0 and 1 of an eligible RGBA plan in ONE launch per direction, the level-0
     low-pass plane handed from wave to wave through LDS (ako_fused.hip.h).  Shapes around every way its workgroups
     (six strips, 704 / 712 net level-0 columns forward / inverse), its level-1 strips, its row segments (multiples of
     6 rows, short first / last segment) and the four borders can fall; DD13/7 and CDF5/3; CLAMP, MIRROR, ZERO; tiled
@@ -401,6 +355,25 @@ def test_fused2_levels_0_and_1_in_one_workgroup_walk(po):
                     assert np.array_equal(bodies[k], blobs[k][16:]), (tag, k)
                     od, _, _ = po.decode_image(blobs[k])
                     assert np.array_equal(back[k], od), (tag, k)
+
+
+def test_shipped_library_ignores_the_measurement_switch(po):
+    """AKO_HIP_DBG selects measurement kernels (loads / stores without arithmetic: garbage output) in -DAKO_MEASURE
+    builds only.  The shipped library neither holds those kernels nor reads the variable: with every bit set it must still
+    give the oracle's bytes, in both directions (hygiene 7a)."""
+    img = po.gen_image(0, 1024, 512, 77)
+    s = po.settings(wavelet=0, wrap=0, compression=2, q=16, g=16)
+    ob, st = po.encode_image(s, img)
+    assert st == 0
+    od, _, _ = po.decode_image(ob)
+    s.color = po.effective_color(s)
+    for dbg in (16, 48, 80, 272, 0xFFFF):
+        with _with_env({"AKO_HIP_DBG": dbg, "AKO_F2_DBG": 7, "AKO_HIP_PATH": "stream"}):
+            assert np.array_equal(hip_encode_body(img, s), ob[16:]), dbg
+            assert np.array_equal(hip_decode_body(ob[16:], s, 4, 1024, 512), od), dbg
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "memonly" not in syms
 
 
 def test_workgroup_shapes_and_lockstep_knobs(po):

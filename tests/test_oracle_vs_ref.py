@@ -211,3 +211,19 @@ def test_kagari_decoder_on_damaged_payloads(po):
                     accepted += 1
                     assert np.array_equal(o1[:values], o2[:values])
     assert accepted > 50
+
+
+def test_private_lift_and_unlift_of_one_plane(po):
+    """The reference's private akoLift / akoUnlift (library/lifting.c:171,295) called on ONE int16 plane the way
+    library/encode.c:132-148 and library/decode.c:183-187 call them: the restatement's lift_plane must give the same
+    stream, and akoUnlift must give the plane back.  (bench.py times exactly these two calls as the CPU baseline of the
+    lifting-only workload, BASELINE.json configs[1].)"""
+    for (w, h) in [(64, 64), (100, 75), (257, 131), (640, 360)]:
+        for wavelet in (0, 1, 2):
+            for wrap in (0, 1, 2, 3):
+                plane = po.gen_plane(w * h, seed=w * 131 + h + wavelet).reshape(h, w)
+                ours = po.lift_plane(wavelet, wrap, plane)
+                theirs = po.ref_lift_plane(wavelet, wrap, plane)
+                assert np.array_equal(ours, theirs), (w, h, wavelet, wrap)
+                assert np.array_equal(po.ref_unlift_plane(wavelet, wrap, w, h, theirs), plane), (w, h, wavelet, wrap)
+                assert np.array_equal(po.unlift_plane(wavelet, wrap, w, h, theirs), plane), (w, h, wavelet, wrap)
