@@ -121,7 +121,7 @@ struct KagariState
 struct Tuning
 {
 	int path = 0;          // AKO_HIP_PATH: 0 auto, 1 generic (window engine), 2 stream wherever legal
-	int tail = 1;          // AKO_HIP_TAIL: 0 none, 1 window-engine tail, 2 segment-engine tail
+	int tail = 2;          // AKO_HIP_TAIL: 0 none, 1 window-engine tail, 2 line-engine tail (ako_tail3.hip.h)
 	int tail_max = 0;      // AKO_HIP_TAIL_MAX: hand only levels this small to the tail (0 = default)
 	bool wide = true;      // AKO_HIP_WIDE=0: no halo-free 121..128 column strips
 	int seg_rows = 0;      // AKO_HIP_SEG_ROWS: rows per segment of the streaming kernels (0 = chosen per level)
@@ -155,7 +155,7 @@ struct Tuning
 		};
 		if (const char* e = getenv("AKO_HIP_PATH"))
 			t.path = (strcmp(e, "generic") == 0) ? 1 : ((strcmp(e, "stream") == 0) ? 2 : 0);
-		t.tail = num("AKO_HIP_TAIL", 1);
+		t.tail = num("AKO_HIP_TAIL", 2);
 		t.tail_max = num("AKO_HIP_TAIL_MAX", 0);
 		t.wide = num("AKO_HIP_WIDE", 1) != 0;
 		t.seg_rows = num("AKO_HIP_SEG_ROWS", 0);
@@ -667,12 +667,26 @@ uint64_t scratch_plane_elems(const Group& g, int which)
 	return (uint64_t)g.levels[which].tw * g.levels[which].th;
 }
 
-// Which tail engine: 1 = window engine (default), 2 = segment engine (kept selectable: measured equal or
-// slower than 1 on every workload of bench.py).  AKO_HIP_TAIL=0 / 1 / 2 forces none / one.
+// Which tail engine: 1 = window engine (any extent up to 128), 2 = line engine (planes resident in LDS from 256 x 256 down,
+// the default).  AKO_HIP_TAIL=0 / 1 / 2 forces none / one.
 int tail_engine(const akoHipPlan* pl, const Group& g)
 {
 	(void)g;
 	return pl->tune.tail;
+}
+
+// line engine: LDS bytes of a tail that starts at level l (0: does not fit a CU's 160 KiB)
+size_t t3_lds_bytes(const akoHipPlan* pl, const Group& g, size_t l)
+{
+	const LevelGeom& L = g.levels[l];
+	if (L.cw > (uint32_t)T3_MAX || L.ch > (uint32_t)T3_MAX)
+		return 0;
+	const int wrap = (int)pl->s.wrap;
+	size_t elems = t3_zero_elems(L.tw, wrap) + t3_level_elems(L.tw, L.th, wrap);
+	if (l + 1 < g.levels.size())
+		elems += t3_level_elems(g.levels[l + 1].tw, g.levels[l + 1].th, wrap);
+	const size_t bytes = elems * sizeof(int16_t) + 16;
+	return bytes <= 160 * 1024 ? bytes : 0;
 }
 
 // first level handled by the fused in-LDS tail kernel (nl = none).  Level 0 of a u8 image never is.
@@ -682,18 +696,18 @@ size_t tail_start(const akoHipPlan* pl, const Group& g)
 	const int engine = tail_engine(pl, g);
 	if (engine == 0)
 		return nl;
-	uint32_t lim = (engine == 2) ? (uint32_t)SEG_TAIL_MAX : (uint32_t)TAIL_MAX;
+	uint32_t lim = (engine == 2) ? (uint32_t)T3_MAX : (uint32_t)TAIL_MAX;
 	if (many_planes(pl) && path_mode(pl) != PATH_GENERIC)
 		lim = (uint32_t)pl->tune.tail_many;  // see stream_eligible(): only what the streaming kernels cannot take
 	if (pl->tune.tail_max >= 4 && (uint32_t)pl->tune.tail_max < lim)  // tuning aid: hand smaller levels only to the tail
 		lim = (uint32_t)pl->tune.tail_max;
 	const bool planes = (pl->flags & AKO_HIP_PLAN_PLANES_I16) != 0;
-	// A launch with few planes (one workgroup each) leaves most of the chip idle, and the tail's first level is its
-	// most expensive: when that level (65..128 samples) can run as a streaming launch of its own, the tail starts one
-	// level later (8192 x 8192 RGBA, 4 planes: levels >= 6 take 113 -> 91 us for both directions)
+	// Window engine: a launch with few planes (one workgroup each) leaves most of the chip idle, and the tail's first
+	// level is its most expensive: when that level (65..128 samples) can run as a streaming launch of its own, the tail
+	// starts one level later (8192 x 8192 RGBA, 4 planes: levels >= 6 take 113 -> 91 us for both directions)
 	const uint64_t n_planes = (uint64_t)pl->channels * g.tiles.size() * pl->batch;
 	for (size_t l = planes ? 0 : 1; l < nl; l++)
-		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim)
+		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim && (engine != 2 || t3_lds_bytes(pl, g, l) != 0))
 		{
 			if (engine == 1 && pl->tune.tail_max == 0 && n_planes <= 32 && l + 1 < nl && l > 0 &&
 			    (g.levels[l].cw > 64 || g.levels[l].ch > 64) && stream_eligible(pl, g.levels[l], false))
@@ -750,7 +764,7 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 	const uint64_t blocks = (uint64_t)g.tiles.size() * pl->batch * pl->channels;
 	if (int rc = check_blocks(blocks))
 		return rc;
-	const bool seg_engine = tail_engine(pl, g) == 2;
+	const bool line_engine = tail_engine(pl, g) == 2;
 	T.pitch = 2 * g.levels[lt].tw;
 	// window engine: LDS and threads by the size of the first (largest) level -- a tiled image has thousands of tiny
 	// planes here (16384 x 16384 in 256-pixel tiles: 16384 planes of 8 x 8), and at the full 48 KB / 1024 threads only
@@ -758,32 +772,33 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 	const LevelGeom& L0t = g.levels[lt];
 	T.win_elems = 2 * (L0t.th + 6) * 2 * (L0t.tw + 8);
 	size_t lds_bytes = ((size_t)T.win_elems + (size_t)L0t.tw * L0t.th) * sizeof(int16_t);
-	if (!seg_engine && lds_bytes > (size_t)TAIL_LDS_BYTES)
-		return fail(AKO_ERROR, "tail level larger than the tail kernel's window%s%s");
 	uint32_t tail_threads = 64;
-	while (tail_threads < (uint32_t)TAIL_THREADS && (uint64_t)tail_threads * 4 < (uint64_t)L0t.cw * L0t.ch)
-		tail_threads *= 2;
-	if (seg_engine)
+	if (line_engine)
 	{
-		lds_bytes = (size_t)(2 * g.levels[lt].th) * T.pitch * sizeof(int16_t);
-		static bool raised = false;  // up to 128 KiB of the CU's 160 KiB: beyond HIP's 64 KiB default
-		if (!raised)
-		{
-			const int cap = SEG_TAIL_MAX * SEG_TAIL_MAX * 2 + 4096;
-			HIP_TRY(hipFuncSetAttribute((const void*)k_forward_tail_seg, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-			HIP_TRY(hipFuncSetAttribute((const void*)k_inverse_tail_seg, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-			raised = true;
-		}
+		// line engine: buffer A = the first level's plane, the rest follows; one wave per four sample rows, 16 at most
+		T.win_elems = t3_level_elems(L0t.tw, L0t.th, (int)pl->s.wrap);
+		lds_bytes = t3_lds_bytes(pl, g, lt);
+		if (lds_bytes == 0)
+			return fail(AKO_ERROR, "tail level larger than the line engine's LDS planes%s%s");
+		const uint32_t waves = (2 * L0t.th + 3) / 4;
+		tail_threads = 64 * (waves < 1 ? 1 : (waves > 16 ? 16 : waves));
+	}
+	else
+	{
+		if (lds_bytes > (size_t)TAIL_LDS_BYTES)
+			return fail(AKO_ERROR, "tail level larger than the tail kernel's window%s%s");
+		while (tail_threads < (uint32_t)TAIL_THREADS && (uint64_t)tail_threads * 4 < (uint64_t)L0t.cw * L0t.ch)
+			tail_threads *= 2;
 	}
 	Launch LA{pl, decode};
 	if (int rc = LA.begin())
 		return rc;
-	if (seg_engine)
+	if (line_engine)
 	{
 		if (decode)
-			hipLaunchKernelGGL(k_inverse_tail_seg, dim3((uint32_t)blocks), dim3(SEGT_THREADS), lds_bytes, pl->stream, T);
+			akoTail3InverseLaunch(T, (uint32_t)blocks, tail_threads, (uint32_t)lds_bytes, pl->stream);
 		else
-			hipLaunchKernelGGL(k_forward_tail_seg, dim3((uint32_t)blocks), dim3(SEGT_THREADS), lds_bytes, pl->stream, T);
+			akoTail3ForwardLaunch(T, (uint32_t)blocks, tail_threads, (uint32_t)lds_bytes, pl->stream);
 	}
 	else
 	{
@@ -793,7 +808,7 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 			hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(tail_threads), lds_bytes, pl->stream, T);
 	}
 	const uint64_t units = samples * blocks;
-	return LA.end(decode ? (seg_engine ? "inv_tail_seg" : "inv_tail") : (seg_engine ? "fwd_tail_seg" : "fwd_tail"),
+	return LA.end(decode ? (line_engine ? "inv_tail_line" : "inv_tail") : (line_engine ? "fwd_tail_line" : "fwd_tail"),
 	              (uint32_t)lt, (uint32_t)gi, units, units * 2, units * 2);
 }
 
