@@ -20,8 +20,9 @@ OBJ = os.path.join(HERE, "csrc", "build")
 # translation units of device code and the headers each one includes (they build in parallel: ako_plan.hip alone takes minutes)
 HIP_SOURCES = {
     "ako_plan.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_tail.hip.h", "ako_tail_params.h", "ako_kagari.hip.h",
-                     "ako_requant.hip.h", "ako_fused.h"],
-    "ako_tail3.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_tail_params.h", "ako_tail3.hip.h"],
+                     "ako_requant.hip.h", "ako_fused.h", "ako_u8.h"],
+    "ako_u8_rgba.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
+    "ako_u8_rgb.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
     "ako_fused.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_fused.h", "ako_fused.hip.h"],
 }
 C_SOURCES = ["host/ako_quant.c", "host/ako_head.c", "host/ako_misc.c", "host/ako_kagari.c", "host/ako_codec.c",

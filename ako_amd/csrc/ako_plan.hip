@@ -7,6 +7,7 @@
 // on the host.
 #include "ako_kernels.hip.h"
 #include "ako_stream.hip.h"
+#include "ako_u8.h"
 #include "ako_tail.hip.h"
 #include "ako_kagari.hip.h"
 #include "ako_requant.hip.h"
@@ -121,14 +122,14 @@ struct KagariState
 struct Tuning
 {
 	int path = 0;          // AKO_HIP_PATH: 0 auto, 1 generic (window engine), 2 stream wherever legal
-	int tail = 2;          // AKO_HIP_TAIL: 0 none, 1 window-engine tail, 2 line-engine tail (ako_tail3.hip.h)
+	int tail = 1;          // AKO_HIP_TAIL: 0 no in-LDS tail, 1 window-engine tail
 	int tail_max = 0;      // AKO_HIP_TAIL_MAX: hand only levels this small to the tail (0 = default)
 	bool wide = true;      // AKO_HIP_WIDE=0: no halo-free 121..128 column strips
 	int seg_rows = 0;      // AKO_HIP_SEG_ROWS: rows per segment of the streaming kernels (0 = chosen per level)
 	int seg_rows_big = 0;  // AKO_HIP_SEG_ROWS_BIG: the same for levels of >= 1024 columns only
 	int seg_rows_small = 0;  // AKO_HIP_SEG_ROWS_SMALL: shortest segment of levels below 1024 columns (0 = default)
 	bool opt = true;       // AKO_HIP_OPT=0: exact int16-wrapping inverse alone (no optimistic fp32 launch)
-	bool staged = true;    // AKO_HIP_STAGED=0: no planar staging of 1-3 / 5+ channel u8 images
+	int staged = 1;        // AKO_HIP_STAGED=0: no planar staging of 1-3 / 5+ channel u8 images; 2: RGB images staged too (not the u8 kernels)
 	bool deep = true;      // AKO_HIP_DEEP=0: small levels keep the running two-slot prefetch
 	int seg_rows_mid = 0, seg_rows_mid_inv = 0;  // AKO_HIP_SEG_ROWS_MID / _MID_INV: same for int16 levels of 1024..2047
 	                                             // columns, forward / inverse kernels
@@ -155,14 +156,14 @@ struct Tuning
 		};
 		if (const char* e = getenv("AKO_HIP_PATH"))
 			t.path = (strcmp(e, "generic") == 0) ? 1 : ((strcmp(e, "stream") == 0) ? 2 : 0);
-		t.tail = num("AKO_HIP_TAIL", 2);
+		t.tail = num("AKO_HIP_TAIL", 1) != 0;
 		t.tail_max = num("AKO_HIP_TAIL_MAX", 0);
 		t.wide = num("AKO_HIP_WIDE", 1) != 0;
 		t.seg_rows = num("AKO_HIP_SEG_ROWS", 0);
 		t.seg_rows_big = num("AKO_HIP_SEG_ROWS_BIG", 0);
 		t.seg_rows_small = num("AKO_HIP_SEG_ROWS_SMALL", 0);
 		t.opt = num("AKO_HIP_OPT", 1) != 0;
-		t.staged = num("AKO_HIP_STAGED", 1) != 0;
+		t.staged = num("AKO_HIP_STAGED", 1);
 		t.deep = num("AKO_HIP_DEEP", 1) != 0;
 		t.u8_waves = num("AKO_HIP_U8_WAVES", 0);
 		t.tail_many = num("AKO_HIP_TAIL_MANY", 16);
@@ -420,6 +421,15 @@ bool stream_width_ok(const akoHipPlan* pl, const LevelGeom& L)
 	return L.tw > (uint32_t)SNET && (L.tw % SNET) != 1 && pl->s.wrap != AKO_WRAP_REPEAT;
 }
 
+// RGB (three channel) u8 images take the u8 streaming kernels too (twelve-byte loads / stores of four pixels) when every
+// tile row starts on a dword and no tile has a ragged four-pixel group: image width (hence every tile width) a multiple
+// of four.  AKO_HIP_STAGED=2 keeps them on the staged route (planar int16 image in front of the int16 kernels).
+bool rgb_native(const akoHipPlan* pl)
+{
+	return pl->channels == 3 && !(pl->flags & AKO_HIP_PLAN_PLANES_I16) && (pl->w % 4) == 0 && pl->tune.staged != 2 &&
+	       (pl->s.tiles_dimension == 0 || (pl->s.tiles_dimension % 4) == 0);
+}
+
 bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 {
 	const int mode = path_mode(pl);
@@ -427,7 +437,7 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 		return false;
 	if (!stream_width_ok(pl, L) || L.th < 2)
 		return false;
-	if (u8 && pl->channels != 4)
+	if (u8 && !(pl->channels == 4 || rgb_native(pl)))
 		return false;
 	// the forward streaming kernels address a tile's stream and the LL scratch planes with 32-bit byte
 	// offsets (raw buffer stores): tiles of 4 GiB and more stay on the window engine
@@ -639,17 +649,12 @@ void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, 
 		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8, OPT, DEEP>), dim3(blocks), threads, 0, st, P, G);
 }
 
-template <bool OPT>
-void launch_inverse_u8(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st)
+void launch_inverse_u8(const akoHipPlan* pl, bool opt, int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks)
 {
-	const dim3 threads(128 * pairs);  // the workgroup is 'pairs' pairs of waves (LDS plane swap inside each pair)
-	const uint32_t lds = pairs * INV_U8_LDS_PER_PAIR;
-	if (kind == K_DD137)
-		hipLaunchKernelGGL((k_inverse_stream_u8<K_DD137, OPT>), dim3(blocks), threads, lds, st, P, G);
-	else if (kind == K_CDF53)
-		hipLaunchKernelGGL((k_inverse_stream_u8<K_CDF53, OPT>), dim3(blocks), threads, lds, st, P, G);
+	if (pl->channels == 3)
+		akoLaunchInverseU8_rgb(kind, opt, P, G, blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 	else
-		hipLaunchKernelGGL((k_inverse_stream_u8<K_HAAR, OPT>), dim3(blocks), threads, lds, st, P, G);
+		akoLaunchInverseU8_rgba(kind, opt, P, G, blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 }
 
 int check_blocks(uint64_t blocks)
@@ -667,26 +672,13 @@ uint64_t scratch_plane_elems(const Group& g, int which)
 	return (uint64_t)g.levels[which].tw * g.levels[which].th;
 }
 
-// Which tail engine: 1 = window engine (any extent up to 128), 2 = line engine (planes resident in LDS from 256 x 256 down,
-// the default).  AKO_HIP_TAIL=0 / 1 / 2 forces none / one.
+// The in-LDS tail (window engine, ako_tail.hip.h): AKO_HIP_TAIL=0 switches it off.  (Two other engines were built and
+// measured equal or slower on every workload -- a register-blocked segment engine in round 2, a row-parallel "line"
+// engine with planes resident from 256 x 256 down in round 3 -- and removed again: DESIGN.md 4.3.)
 int tail_engine(const akoHipPlan* pl, const Group& g)
 {
 	(void)g;
 	return pl->tune.tail;
-}
-
-// line engine: LDS bytes of a tail that starts at level l (0: does not fit a CU's 160 KiB)
-size_t t3_lds_bytes(const akoHipPlan* pl, const Group& g, size_t l)
-{
-	const LevelGeom& L = g.levels[l];
-	if (L.cw > (uint32_t)T3_MAX || L.ch > (uint32_t)T3_MAX)
-		return 0;
-	const int wrap = (int)pl->s.wrap;
-	size_t elems = t3_zero_elems(L.tw, wrap) + t3_level_elems(L.tw, L.th, wrap);
-	if (l + 1 < g.levels.size())
-		elems += t3_level_elems(g.levels[l + 1].tw, g.levels[l + 1].th, wrap);
-	const size_t bytes = elems * sizeof(int16_t) + 16;
-	return bytes <= 160 * 1024 ? bytes : 0;
 }
 
 // first level handled by the fused in-LDS tail kernel (nl = none).  Level 0 of a u8 image never is.
@@ -696,7 +688,7 @@ size_t tail_start(const akoHipPlan* pl, const Group& g)
 	const int engine = tail_engine(pl, g);
 	if (engine == 0)
 		return nl;
-	uint32_t lim = (engine == 2) ? (uint32_t)T3_MAX : (uint32_t)TAIL_MAX;
+	uint32_t lim = (uint32_t)TAIL_MAX;
 	if (many_planes(pl) && path_mode(pl) != PATH_GENERIC)
 		lim = (uint32_t)pl->tune.tail_many;  // see stream_eligible(): only what the streaming kernels cannot take
 	if (pl->tune.tail_max >= 4 && (uint32_t)pl->tune.tail_max < lim)  // tuning aid: hand smaller levels only to the tail
@@ -707,7 +699,7 @@ size_t tail_start(const akoHipPlan* pl, const Group& g)
 	// starts one level later (8192 x 8192 RGBA, 4 planes: levels >= 6 take 113 -> 91 us for both directions)
 	const uint64_t n_planes = (uint64_t)pl->channels * g.tiles.size() * pl->batch;
 	for (size_t l = planes ? 0 : 1; l < nl; l++)
-		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim && (engine != 2 || t3_lds_bytes(pl, g, l) != 0))
+		if (g.levels[l].cw <= lim && g.levels[l].ch <= lim)
 		{
 			if (engine == 1 && pl->tune.tail_max == 0 && n_planes <= 32 && l + 1 < nl && l > 0 &&
 			    (g.levels[l].cw > 64 || g.levels[l].ch > 64) && stream_eligible(pl, g.levels[l], false))
@@ -764,52 +756,27 @@ int run_tail(akoHipPlan* pl, int gi, size_t lt, int decode, void* d_images, int1
 	const uint64_t blocks = (uint64_t)g.tiles.size() * pl->batch * pl->channels;
 	if (int rc = check_blocks(blocks))
 		return rc;
-	const bool line_engine = tail_engine(pl, g) == 2;
 	T.pitch = 2 * g.levels[lt].tw;
-	// window engine: LDS and threads by the size of the first (largest) level -- a tiled image has thousands of tiny
-	// planes here (16384 x 16384 in 256-pixel tiles: 16384 planes of 8 x 8), and at the full 48 KB / 1024 threads only
-	// three of them fit a CU at a time
+	// LDS and threads by the size of the first (largest) level -- a tiled image has thousands of tiny planes here
+	// (16384 x 16384 in 256-pixel tiles: 16384 planes of 8 x 8), and at the full 48 KB / 1024 threads only three of them
+	// fit a CU at a time
 	const LevelGeom& L0t = g.levels[lt];
 	T.win_elems = 2 * (L0t.th + 6) * 2 * (L0t.tw + 8);
-	size_t lds_bytes = ((size_t)T.win_elems + (size_t)L0t.tw * L0t.th) * sizeof(int16_t);
+	const size_t lds_bytes = ((size_t)T.win_elems + (size_t)L0t.tw * L0t.th) * sizeof(int16_t);
+	if (lds_bytes > (size_t)TAIL_LDS_BYTES)
+		return fail(AKO_ERROR, "tail level larger than the tail kernel's window%s%s");
 	uint32_t tail_threads = 64;
-	if (line_engine)
-	{
-		// line engine: buffer A = the first level's plane, the rest follows; one wave per four sample rows, 16 at most
-		T.win_elems = t3_level_elems(L0t.tw, L0t.th, (int)pl->s.wrap);
-		lds_bytes = t3_lds_bytes(pl, g, lt);
-		if (lds_bytes == 0)
-			return fail(AKO_ERROR, "tail level larger than the line engine's LDS planes%s%s");
-		const uint32_t waves = (2 * L0t.th + 3) / 4;
-		tail_threads = 64 * (waves < 1 ? 1 : (waves > 16 ? 16 : waves));
-	}
-	else
-	{
-		if (lds_bytes > (size_t)TAIL_LDS_BYTES)
-			return fail(AKO_ERROR, "tail level larger than the tail kernel's window%s%s");
-		while (tail_threads < (uint32_t)TAIL_THREADS && (uint64_t)tail_threads * 4 < (uint64_t)L0t.cw * L0t.ch)
-			tail_threads *= 2;
-	}
+	while (tail_threads < (uint32_t)TAIL_THREADS && (uint64_t)tail_threads * 4 < (uint64_t)L0t.cw * L0t.ch)
+		tail_threads *= 2;
 	Launch LA{pl, decode};
 	if (int rc = LA.begin())
 		return rc;
-	if (line_engine)
-	{
-		if (decode)
-			akoTail3InverseLaunch(T, (uint32_t)blocks, tail_threads, (uint32_t)lds_bytes, pl->stream);
-		else
-			akoTail3ForwardLaunch(T, (uint32_t)blocks, tail_threads, (uint32_t)lds_bytes, pl->stream);
-	}
+	if (decode)
+		hipLaunchKernelGGL(k_inverse_tail, dim3((uint32_t)blocks), dim3(tail_threads), lds_bytes, pl->stream, T);
 	else
-	{
-		if (decode)
-			hipLaunchKernelGGL(k_inverse_tail, dim3((uint32_t)blocks), dim3(tail_threads), lds_bytes, pl->stream, T);
-		else
-			hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(tail_threads), lds_bytes, pl->stream, T);
-	}
+		hipLaunchKernelGGL(k_forward_tail, dim3((uint32_t)blocks), dim3(tail_threads), lds_bytes, pl->stream, T);
 	const uint64_t units = samples * blocks;
-	return LA.end(decode ? (line_engine ? "inv_tail_line" : "inv_tail") : (line_engine ? "fwd_tail_line" : "fwd_tail"),
-	              (uint32_t)lt, (uint32_t)gi, units, units * 2, units * 2);
+	return LA.end(decode ? "inv_tail" : "fwd_tail", (uint32_t)lt, (uint32_t)gi, units, units * 2, units * 2);
 }
 
 int run_format(akoHipPlan* pl, int gi, int decode, uint8_t* img, int16_t* stream, bool planar = false)
@@ -868,6 +835,8 @@ bool staged_level0(const akoHipPlan* pl, const Group& g)
 {
 	if ((pl->flags & AKO_HIP_PLAN_PLANES_I16) || pl->channels == 4 || g.levels.empty())
 		return false;
+	if (rgb_native(pl) && stream_eligible(pl, g.levels[0], true))
+		return false;  // the u8 kernels take RGB themselves
 	if (pl->s.wavelet == AKO_WAVELET_NONE || path_mode(pl) == PATH_GENERIC)
 		return false;
 	if (!pl->tune.staged)
@@ -1006,15 +975,10 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					hipLaunchKernelGGL(k_forward_stream_i16_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
 				else
 #endif
-				if (u8)
-				{
-					if (L.kind == K_DD137)
-						hipLaunchKernelGGL((k_forward_stream_u8<K_DD137>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
-					else if (L.kind == K_CDF53)
-						hipLaunchKernelGGL((k_forward_stream_u8<K_CDF53>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
-					else
-						hipLaunchKernelGGL((k_forward_stream_u8<K_HAAR>), dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
-				}
+				if (u8 && pl->channels == 3)
+					akoLaunchForwardU8_rgb(L.kind, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
+				else if (u8)
+					akoLaunchForwardU8_rgba(L.kind, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_forward_stream<1, false, DEEP_SLOTS_SHORT>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep)
@@ -1184,7 +1148,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 						hipLaunchKernelGGL(k_inverse_stream_u8_memonly, dim3((uint32_t)blocks), dim3(128 * (uint32_t)pl->tune.inv_pairs), 0, pl->stream, P, G);
 					else
 #endif
-						launch_inverse_u8<true>(L.kind, P, G, (uint32_t)blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
+						launch_inverse_u8(pl, true, L.kind, P, G, (uint32_t)blocks);
 					snprintf(name, sizeof name, "inv_stream_%s_u8", kind_name(L.kind));
 					const uint64_t smp = (uint64_t)L.cw * L.ch * pl->channels * insts;
 					const uint64_t ins = ((uint64_t)4 * L.tw * L.th + 1) * pl->channels * insts;
@@ -1194,7 +1158,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				if (int rc = LA.begin())
 					return rc;
 				if (u8)
-					launch_inverse_u8<false>(L.kind, P, G, (uint32_t)blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
+					launch_inverse_u8(pl, false, L.kind, P, G, (uint32_t)blocks);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_inverse_stream<1, false, false, DEEP_SLOTS_SHORT>(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep)

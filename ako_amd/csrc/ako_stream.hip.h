@@ -942,6 +942,12 @@ __device__ __forceinline__ uint32_t pixel_u8x4(float r, float g, float b, float 
 	w = __builtin_amdgcn_cvt_pk_u8_f32(b, 2, w);
 	return __builtin_amdgcn_cvt_pk_u8_f32(a, 3, w);
 }
+// four RGBx pixels (fourth byte zero) -> twelve bytes of RGB
+__device__ __forceinline__ auto rgb_pack4(const uint32_t px[4])
+{
+	typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+	return u32x3{px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+}
 // acc = max(acc, |a|, |b|) in one instruction (fmaxf() would first canonicalise each operand)
 __device__ __forceinline__ void absmax3(float& acc, float a, float b)
 {
@@ -987,10 +993,13 @@ struct FwdRaw<false>
 // loads in flight at once the segment costs one round trip.  (A single pass over exactly N slots: the ring indices
 // of the column pipeline stay compile-time constants for any N.)
 template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE, int DEEP, bool CFAST = false, int PF = 2, int LATE = 0,
-          bool MEMONLY = false>
+          bool MEMONLY = false, int CH = 4>
 __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
                                                     const LaneCols& lc, int lane)
 {
+	static_assert(CH == 4 || (CH == 3 && U8 && NPL == 2), "CH = 3: the u8 kernels on RGB pixels");
+	// CH = 3 (RGB): the pair's second wave owns planes 1 and 3, and plane 3 does not exist: it carries one plane
+	const bool one_plane = (CH == 3) && (id.pg == 1);
 	const TileDesc td = P.tiles[id.tile];
 	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
 	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
@@ -1014,8 +1023,8 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	uint32_t row_pitch_b;  // bytes per row
 	if (U8)
 	{
-		src_base = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * 4;
-		row_pitch_b = P.img_pitch * 4u;
+		src_base = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * CH;
+		row_pitch_b = P.img_pitch * (uint32_t)CH;
 	}
 	else
 	{
@@ -1026,7 +1035,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		row_pitch_b = P.src_pitch * 2u;
 	}
 	const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_base), 0, (int)0xFFFFFFFFu, 0x00020000);
-	const uint32_t src_lane_off = (uint32_t)lc.xs * (U8 ? 4u : 2u);
+	const uint32_t src_lane_off = (uint32_t)lc.xs * (U8 ? (uint32_t)CH : 2u);
 
 	// destinations.  Stream and LL stores go through raw buffer resources: a lane or a row that must not
 	// store gets an out-of-range offset and the hardware drops the write (scripts/probe_buffer_store.hip;
@@ -1065,7 +1074,8 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	if (id.strip == 0 && id.seg == 0 && lane == 0)
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
-			tile_stream[P.grp_off[p_first + p * P_STEP]] = (int16_t)((p_first + p * P_STEP == 0) ? P.q_luma : P.q_chroma);
+			if (!(one_plane && p == 1))
+				tile_stream[P.grp_off[p_first + p * P_STEP]] = (int16_t)((p_first + p * P_STEP == 0) ? P.q_luma : P.q_chroma);
 
 	const float gf_luma = (float)P.g_luma, gf_chroma = (float)P.g_chroma;
 
@@ -1092,7 +1102,13 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				raw.a[par] = RawVec{};
 				continue;
 			}
-			if constexpr (U8)
+			if constexpr (U8 && CH == 3)
+			{
+				typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+				const u32x3 t = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(rs_src, src_lane_off, row_off, AUX_FWD_PIXEL_LOAD));
+				raw.a[par] = RawVec{t.x, t.y, t.z, 0u};
+			}
+			else if constexpr (U8)
 				raw.a[par] = __builtin_bit_cast(RawVec, __builtin_amdgcn_raw_buffer_load_b128(rs_src, src_lane_off, row_off, AUX_FWD_PIXEL_LOAD));
 			else
 				raw.a[par] = __builtin_bit_cast(RawVec, __builtin_amdgcn_raw_buffer_load_b64(rs_src, src_lane_off, row_off, 0));
@@ -1154,12 +1170,20 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			{
 				if constexpr (U8)
 				{
-					const uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
+					uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
+					if constexpr (CH == 3)
+					{
+						// twelve bytes = four RGB pixels: each into the low three bytes of a dword (the fourth byte, read as
+						// "alpha" by the decoders, belongs to the plane this wave does not carry)
+						px[3] = raw.a[par].z >> 8;
+						px[2] = __builtin_amdgcn_alignbit(raw.a[par].z, raw.a[par].y, 16);
+						px[1] = __builtin_amdgcn_alignbit(raw.a[par].y, raw.a[par].x, 24);
+					}
 					V v0[4], v1[4];
 					if constexpr (CFAST)
 						decode_pixels_ycocg<V>(px, (P.color == C_YCOCG_Q) ? (V)2 : (V)1, (int)id.pg, v0, v1);
 					else
-						decode_pixels_pair<V>(px, P.color, (int)id.pg, P.discard != 0, v0, v1);
+						decode_pixels_pair<V>(px, P.color, (int)id.pg, (CH == 4) && P.discard != 0, v0, v1);
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 					{
@@ -1189,10 +1213,12 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			raw_consumed();
 
 			const int r = v - 3;
-			uint32_t w_ll[NPL], w_c[NPL], w_b[NPL], w_d[NPL];
+			uint32_t w_ll[NPL] = {}, w_c[NPL] = {}, w_b[NPL] = {}, w_d[NPL] = {};
 #pragma unroll
 			for (int p = 0; p < NPL; p++)
 			{
+				if (one_plane && p == 1)  // wave-uniform
+					continue;
 				V e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
 				hlift_forward<KIND, NARROW, HEDGE, V>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], lc.he,
 				                                      e[0], e[1], e[2], e[3]);
@@ -1216,6 +1242,8 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 #pragma unroll
 				for (int p = 0; p < NPL; p++)
 				{
+					if (one_plane && p == 1)
+						continue;
 					const uint32_t s_ll = row_ok ? ll_off[p] + row_ll : OOB;
 					const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
 					const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
@@ -1368,7 +1396,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream_i16_memonly(const Le
 }
 #endif  // AKO_MEASURE
 
-template <int KIND>
+template <int KIND, int CH = 4>  // CH: bytes per pixel = channels (4 RGBA, 3 RGB)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_forward_stream_u8(const LevelParams P, const StreamGeom G)
 {
 	const UnitId id = decode_unit(P, G);
@@ -1383,9 +1411,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	do                                                                                                 \
 	{                                                                                                  \
 		if (cfast)                                                                                     \
-			forward_stream_body<KIND, 2, true, false, H, V, 0, true, 2, U8_RING>(P, G, id, lc, lane);             \
+			forward_stream_body<KIND, 2, true, false, H, V, 0, true, 2, U8_RING, false, CH>(P, G, id, lc, lane);  \
 		else                                                                                           \
-			forward_stream_body<KIND, 2, true, false, H, V, 0, false, 2, U8_RING>(P, G, id, lc, lane);            \
+			forward_stream_body<KIND, 2, true, false, H, V, 0, false, 2, U8_RING, false, CH>(P, G, id, lc, lane); \
 	} while (0)
 	if (__builtin_expect(vedge, 0))
 	{
@@ -1430,11 +1458,14 @@ struct InvRaw
 constexpr float OPT_INPUT_BOUND = 3560.0f;
 constexpr float OPT_OUTPUT_BOUND = 10921.0f;
 
-template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE, int DEEP, int PF = 2, bool MEMONLY = false>
+template <int KIND, int NPL, bool U8, bool OPT, bool HEDGE, bool VEDGE, int DEEP, int PF = 2, bool MEMONLY = false, int CH = 4>
 __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
                                                     const LaneCols& lc, int lane, uint4 (*xbuf)[2][2][64])
 {
 	static_assert(!OPT || U8, "the optimistic pipeline is used on the u8 side only");
+	static_assert(CH == 4 || (CH == 3 && U8 && NPL == 2), "CH = 3: the u8 kernels on RGB pixels");
+	// CH = 3 (RGB): the pair's second wave owns planes 2 and 3, and plane 3 does not exist: it carries one plane
+	const bool one_plane = (CH == 3) && (id.pg == 1);
 	using V = std::conditional_t<OPT, float, int>;
 	float peak_in = 0.0f, peak_out = 0.0f;
 	const TileDesc td = P.tiles[id.tile];
@@ -1466,7 +1497,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
 	{
-		const int pl = p_first + p;
+		const int pl = (one_plane && p == 1) ? p_first : p_first + p;  // (the absent plane: any valid offsets, never used)
 		qv[p] = tile_stream[P.grp_off[pl]];  // the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116)
 		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1) * 2);
 		ll_off[p] = (uint32_t)((P.ll_in_stream ? P.lp_off[pl] : (uint64_t)pl * P.src_plane_stride) * 2);
@@ -1478,8 +1509,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	uint64_t out_pitch;
 	if (U8)
 	{
-		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * 4;  // tile origin
-		out_pitch = (uint64_t)P.img_pitch * 4;
+		img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * CH;  // tile origin
+		out_pitch = (uint64_t)P.img_pitch * CH;
 	}
 	else
 	{
@@ -1496,7 +1527,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	// that is out of range in a lane that must not store, the row is the scalar offset (0xFFFFFFFF: row dropped)
 	constexpr uint32_t OOB = 0xFFFFFFFFu;
 	const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(U8 ? (void*)img : (void*)nullptr, 0, U8 ? (int)0xFFFFFFFFu : 0, RSRC_FLAGS);
-	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * c0) * 4u : OOB;
+	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * c0) * (uint32_t)CH : OOB;
 	(void)rs_img, (void)px_lane_off;
 
 	VInv<V> st[NPL][4];
@@ -1520,6 +1551,11 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
 		{
+			if (one_plane && p == 1)  // wave-uniform
+			{
+				raw.ll[p] = raw.c[p] = raw.b[p] = raw.d[p] = 0u;
+				continue;
+			}
 			const uint32_t g = grp_off[p] + row_g;
 			raw.ll[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_ll, lane_in_off, ll_off[p] + row_l, 0);
 			raw.c[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g, AUX_INV_STREAM_LOAD);
@@ -1550,10 +1586,12 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				return;
 			}
 			const bool store_row = (r >= r_lo) && (r < r_hi) && store_lane;
-			V out[2][NPL][4];  // [row parity][plane][E0 O0 E1 O1]
+			V out[2][NPL][4] = {};  // [row parity][plane][E0 O0 E1 O1]
 #pragma unroll
 			for (int p = 0; p < NPL; p++)
 			{
+				if (one_plane && p == 1)  // wave-uniform
+					continue;
 				// columns: 0,1 = row low-pass columns c0, c1 (LL over C); 2,3 = row high-pass (B over D)
 				V lpv[4], hpv[4];
 				if constexpr (OPT)  // float pipe: sign-extending word selects on the conversions (unpack2_f)
@@ -1660,7 +1698,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						{
 							float rr, gg, bb;
 							color_inverse_fast(P.color, his0[k], his1[k], out[1][0][k], rr, gg, bb);
-							px[k] = pixel_u8x4(rr, gg, bb, out[1][1][k]);
+							px[k] = pixel_u8x4(rr, gg, bb, (CH == 3) ? 0.0f : out[1][1][k]);
 						}
 					}
 					else
@@ -1670,13 +1708,15 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						{
 							float rr, gg, bb;
 							color_inverse_fast(P.color, out[0][0][k], out[0][1][k], his0[k], rr, gg, bb);
-							px[k] = pixel_u8x4(rr, gg, bb, his1[k]);
+							px[k] = pixel_u8x4(rr, gg, bb, (CH == 3) ? 0.0f : his1[k]);
 						}
 					}
 					const uint32_t s_row = (uint32_t)y * (uint32_t)out_pitch;
 					typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 					typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-					if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
+					if constexpr (CH == 3)  // four RGB pixels = twelve bytes (widths here are multiples of four pixels)
+						__builtin_amdgcn_raw_buffer_store_b96(rgb_pack4(px), rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
+					else if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
 						__builtin_amdgcn_raw_buffer_store_b96(u32x3{px[0], px[1], px[2]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
 					else
 						__builtin_amdgcn_raw_buffer_store_b128(u32x4{px[0], px[1], px[2], px[3]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
@@ -1710,10 +1750,16 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						int rr, gg, bb;
 						color_inverse((int)P.color, (int)v0, (int)v1, (int)v2, rr, gg, bb);
 						px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
-						        ((uint32_t)sat8((int)v3) << 24);
+						        ((CH == 3) ? 0u : ((uint32_t)sat8((int)v3) << 24));
 					}
-					uint8_t* row = img + (uint64_t)y * out_pitch + (int64_t)(2 * c0) * 4;
-					if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
+					uint8_t* row = img + (uint64_t)y * out_pitch + (int64_t)(2 * c0) * CH;
+					if constexpr (CH == 3)
+					{
+						const auto w3 = rgb_pack4(px);
+						uint32_t* o = reinterpret_cast<uint32_t*>(row);
+						o[0] = w3.x, o[1] = w3.y, o[2] = w3.z;
+					}
+					else if (HEDGE && lc.he.drop_last)  // odd width: the fourth pixel does not exist
 					{
 						uint32_t* o = reinterpret_cast<uint32_t*>(row);
 						o[0] = px[0], o[1] = px[1], o[2] = px[2];
@@ -1819,7 +1865,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 // (StreamGeom::lockstep); 8 KB of dynamic LDS per pair.
 // OPT = optimistic fp32 pipeline; the exact re-run behind it (OPT = false) returns at once unless flagged.
 constexpr uint32_t INV_U8_LDS_PER_PAIR = 2 * 2 * 2 * 64 * sizeof(uint4);
-template <int KIND, bool OPT>
+template <int KIND, bool OPT, int CH = 4>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_inverse_stream_u8(const LevelParams P, const StreamGeom G)
 {
 	extern __shared__ uint4 xdyn[];  // [pair of the workgroup][slot parity][destination wave of the pair][plane][lane]
@@ -1838,16 +1884,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	if (__builtin_expect(vedge, 0))
 	{
 		if (lc.hedge)
-			inverse_stream_body<KIND, 2, true, OPT, true, true, 0, 2>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, true, true, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, 2, true, OPT, false, true, 0, 2>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, false, true, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
 	}
 	else
 	{
 		if (lc.hedge)
-			inverse_stream_body<KIND, 2, true, OPT, true, false, 0, 2>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, true, false, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, 2, true, OPT, false, false, 0, 2>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, false, false, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
 	}
 }
 

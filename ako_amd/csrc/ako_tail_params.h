@@ -1,5 +1,4 @@
-// ako_tail_params.h -- parameters of the in-LDS tail kernels (ako_tail.hip.h: window / segment engines;
-// ako_tail3.hip.h: line engine), shared by the translation units that launch and define them.
+// ako_tail_params.h -- parameters of the in-LDS tail kernels (ako_tail.hip.h).
 #pragma once
 
 #include "ako_kernels.hip.h"
@@ -41,28 +40,5 @@ struct TailParams
 	uint32_t fw, fh;          // final low-pass extent; plane p's low-pass sits at p * fw * fh
 };
 
-
-// ---- line engine (ako_tail3.hip.h): geometry shared with the host ----
-constexpr int T3_MAX = 256;  // largest level extent in samples, either direction
-
-// int16 elements per row of a level with tc coefficient columns: a multiple of four (rows stay 8-byte aligned for the
-// lanes' 8-byte accesses); ZERO borders keep four zero samples behind the row
-__host__ __device__ inline uint32_t t3_pitch(uint32_t tc, int wrap)
-{
-	return ((2 * tc + 3u) & ~3u) + ((wrap == W_ZERO) ? 4u : 0u);
-}
-__host__ __device__ inline uint32_t t3_level_elems(uint32_t tc, uint32_t tr, int wrap)
-{
-	return 2 * tr * t3_pitch(tc, wrap);
-}
-// int16 elements of LDS in front of buffer A: a row of zeros for ZERO borders
-__host__ __device__ inline uint32_t t3_zero_elems(uint32_t tc0, int wrap)
-{
-	return (wrap == W_ZERO) ? t3_pitch(tc0, wrap) : 0u;
-}
-
-// line engine (ako_tail3.hip): launchers
-void akoTail3ForwardLaunch(const TailParams& P, uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t st);
-void akoTail3InverseLaunch(const TailParams& P, uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t st);
 
 }  // namespace ako

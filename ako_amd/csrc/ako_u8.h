@@ -1,0 +1,15 @@
+// ako_u8.h -- launchers of the u8 level-0 streaming kernels (k_forward_stream_u8 / k_inverse_stream_u8 of
+// ako_stream.hip.h), one translation unit per pixel format so that they build in parallel with ako_plan.hip:
+// ako_u8_rgba.hip (four bytes per pixel) and ako_u8_rgb.hip (three).  Include after ako_stream.hip.h.
+#pragma once
+
+namespace ako
+{
+
+void akoLaunchForwardU8_rgba(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
+void akoLaunchForwardU8_rgb(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
+// opt: the optimistic fp32 pipeline (false: the exact int16-wrapping kernel, which returns at once unless flagged)
+void akoLaunchInverseU8_rgba(int kind, bool opt, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
+void akoLaunchInverseU8_rgb(int kind, bool opt, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
+
+}  // namespace ako

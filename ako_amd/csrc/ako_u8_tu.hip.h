@@ -1,0 +1,39 @@
+// ako_u8_tu.hip.h -- body of ako_u8_rgba.hip / ako_u8_rgb.hip: AKO_U8_CH = bytes per pixel, AKO_U8_NAME(x) = x ## _rgba / _rgb
+#include "ako_stream.hip.h"
+#include "ako_u8.h"
+
+namespace ako
+{
+
+void AKO_U8_NAME(akoLaunchForwardU8)(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st)
+{
+	if (kind == K_DD137)
+		hipLaunchKernelGGL((k_forward_stream_u8<K_DD137, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
+	else if (kind == K_CDF53)
+		hipLaunchKernelGGL((k_forward_stream_u8<K_CDF53, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
+	else
+		hipLaunchKernelGGL((k_forward_stream_u8<K_HAAR, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
+}
+
+template <bool OPT>
+static void launch_inverse(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st)
+{
+	const dim3 threads(128 * pairs);  // the workgroup is 'pairs' pairs of waves (LDS plane swap inside each pair)
+	const uint32_t lds = pairs * INV_U8_LDS_PER_PAIR;
+	if (kind == K_DD137)
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_DD137, OPT, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
+	else if (kind == K_CDF53)
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_CDF53, OPT, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
+	else
+		hipLaunchKernelGGL((k_inverse_stream_u8<K_HAAR, OPT, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
+}
+
+void AKO_U8_NAME(akoLaunchInverseU8)(int kind, bool opt, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st)
+{
+	if (opt)
+		launch_inverse<true>(kind, P, G, blocks, pairs, st);
+	else
+		launch_inverse<false>(kind, P, G, blocks, pairs, st);
+}
+
+}  // namespace ako

@@ -15,5 +15,5 @@ PLAN=$O/ako_plan.hip.o; FUSED=$O/ako_fused.hip.o
 if [ $WHICH != fused ]; then PLAN=$O/ako_plan_$NAME.o; $CC "$@" -c ako_amd/csrc/ako_plan.hip -o $PLAN & fi
 if [ $WHICH != plan ]; then FUSED=$O/ako_fused_$NAME.o; $CC "$@" -c ako_amd/csrc/ako_fused.hip -o $FUSED & fi
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ako_amd/libako_$NAME.so $PLAN $FUSED $O/ako_tail3.hip.o $O/ako_quant.c.o $O/ako_head.c.o $O/ako_misc.c.o $O/ako_kagari.c.o $O/ako_codec.c.o $O/ako_synth.c.o $O/ako_batch.c.o -lm -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ako_amd/libako_$NAME.so $PLAN $FUSED $O/ako_u8_rgba.hip.o $O/ako_u8_rgb.hip.o $O/ako_quant.c.o $O/ako_head.c.o $O/ako_misc.c.o $O/ako_kagari.c.o $O/ako_codec.c.o $O/ako_synth.c.o $O/ako_batch.c.o -lm -lpthread
 echo built ako_amd/libako_$NAME.so

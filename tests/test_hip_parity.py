@@ -43,7 +43,7 @@ def hip_decode_body(body, s, ch, w, h):
 
 
 @pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt",
-                        "stream-tail1", "stream-tail2", "stream-nostaged", "auto-fuse2", "stream-fuse2"])
+                        "stream-tail1", "stream-nostaged", "auto-fuse2", "stream-fuse2"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
     kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
@@ -52,14 +52,12 @@ def path_mode(request):
     old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE2")}
     mode = request.param
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
-    # AKO_HIP_TAIL: 0 no fused tail, 1 window-engine tail, 2 segment-engine tail, unset = chosen per launch
+    # AKO_HIP_TAIL: 0 no in-LDS tail, 1 (default) the window-engine tail
     os.environ.pop("AKO_HIP_TAIL", None)
     if mode.endswith("notail"):
         os.environ["AKO_HIP_TAIL"] = "0"
     elif mode.endswith("tail1"):
         os.environ["AKO_HIP_TAIL"] = "1"
-    elif mode.endswith("tail2"):
-        os.environ["AKO_HIP_TAIL"] = "2"
     os.environ["AKO_HIP_OPT"] = "0" if mode.endswith("noopt") else "1"   # optimistic fp32 inverse on / off
     # '-nostaged': u8 images with 1-3 / 5+ channels keep the window engine on level 0 instead of the
     # u8 -> planar int16 staging in front of the int16 streaming kernels
@@ -309,7 +307,7 @@ def _with_env(env):
 def test_fused2_levels_0_and_1_in_one_workgroup_walk(po):
     """AKO_HIP_FUSE2=3 (off by default): levels 0 and 1 of an eligible RGBA plan in ONE launch per direction, the level-0
     low-pass plane handed from wave to wave through LDS (ako_fused.hip.h).  Shapes around every way its workgroups
-    (six strips, 704 / 712 net level-0 columns forward / inverse), its level-1 strips, its row segments (multiples of
+    (four strips, 464 / 472 net level-0 columns forward / inverse), its level-1 strips, its row segments (multiples of
     6 rows, short first / last segment) and the four borders can fall; DD13/7 and CDF5/3; CLAMP, MIRROR, ZERO; tiled
     and batched; gates and quantizers -- streams byte-for-byte against the oracle, decoded pixels bit-exact, and the
     kernel records must show that the fused kernels are what ran."""
@@ -374,6 +372,45 @@ def test_shipped_library_ignores_the_measurement_switch(po):
     import subprocess
     syms = subprocess.run(["nm", "-D", "--defined-only", api.LIB_PATH], capture_output=True, text=True).stdout
     assert "memonly" not in syms
+
+
+def test_rgb_images_take_the_u8_kernels(po):
+    """Three-channel u8 images whose width is a multiple of four pixels run level 0 on the u8 streaming kernels
+    (twelve-byte loads / stores of four RGB pixels, the pair's second wave carrying one plane) instead of being staged
+    through a planar int16 image: no u8_to_planes / planes_to_u8 launch, the oracle's bytes in both directions -- all
+    wavelets, wraps, colour modes, tiled and not, strips and segments with every kind of border.  Other widths and
+    AKO_HIP_STAGED=2 keep the staged route (reference: library/format.c:64-134,244-311 does any channel count in one pass)."""
+    nrng = np.random.default_rng(333)
+    cases = [(256, 64, 0), (1000, 300, 0), (1364, 200, 0), (2048, 96, 0), (1024, 512, 256), (640, 480, 128), (4096, 64, 0),
+             (1002, 120, 0), (777, 131, 0)]
+    for (w, h, tiles) in cases:
+        for wavelet in (0, 1, 2):
+            for staged in (1, 2):
+                wrap = int(nrng.integers(0, 4))
+                q = int(nrng.choice([0, 1, 16, 40]))
+                g = int(nrng.choice([0, 0, 16]))
+                color = int(nrng.choice([0, 1, 2]))
+                img = nrng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+                s = po.settings(wavelet=wavelet, wrap=wrap, color=color, compression=2, q=q, g=g, tiles=tiles)
+                ob, st = po.encode_image(s, img)
+                assert st == 0
+                od, _, _ = po.decode_image(ob)
+                s.color = po.effective_color(s)
+                with _with_env({"AKO_HIP_PATH": "stream", "AKO_HIP_STAGED": staged}):
+                    with api.Plan(_to_api(s), 3, w, h) as plan:
+                        plan.set_profiling(True)
+                        d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(img)[None]).cuda())
+                        d_back = plan.decode(d_streams)
+                        plan.synchronize()
+                        names = [r["name"] for r in plan.kernel_records(False)] + [r["name"] for r in plan.kernel_records(True)]
+                        body = d_streams.cpu().numpy().reshape(-1).view(np.uint8)
+                        back = d_back.cpu().numpy().reshape(h, w, 3)
+                tag = (w, h, tiles, wavelet, wrap, q, g, color, staged)
+                native = (w % 4 == 0) and staged == 1
+                assert any(n.endswith("_u8") for n in names) == native, (tag, names)
+                assert any(n in ("u8_to_planes", "planes_to_u8") for n in names) == (not native), (tag, names)
+                assert np.array_equal(body, ob[16:]), tag
+                assert np.array_equal(back, od), tag
 
 
 def test_workgroup_shapes_and_lockstep_knobs(po):
