@@ -407,8 +407,9 @@ def test_rgb_images_take_the_u8_kernels(po):
                         back = d_back.cpu().numpy().reshape(h, w, 3)
                 tag = (w, h, tiles, wavelet, wrap, q, g, color, staged)
                 native = (w % 4 == 0) and staged == 1
-                assert any(n.endswith("_u8") for n in names) == native, (tag, names)
-                assert any(n in ("u8_to_planes", "planes_to_u8") for n in names) == (not native), (tag, names)
+                assert any(n.startswith(("fwd_stream_", "inv_stream_")) and n.endswith("_u8") for n in names) == native, (tag, names)
+                if native:  # (the other shapes are staged where the int16 kernels can take level 0, else on the window engine)
+                    assert not any(n in ("u8_to_planes", "planes_to_u8") for n in names), (tag, names)
                 assert np.array_equal(body, ob[16:]), tag
                 assert np.array_equal(back, od), tag
 
