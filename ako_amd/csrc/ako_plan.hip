@@ -970,9 +970,9 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					return rc;
 #ifdef AKO_MEASURE
 				if (u8 && (pl->tune.dbg & 16))
-					hipLaunchKernelGGL(k_forward_stream_u8_memonly, dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
+					hipLaunchKernelGGL(k_forward_stream_u8_memonly<>, dim3((uint32_t)blocks), dim3(64 * waves_per_block), 0, pl->stream, P, G);
 				else if (!u8 && (pl->tune.dbg & 16))
-					hipLaunchKernelGGL(k_forward_stream_i16_memonly, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
+					hipLaunchKernelGGL(k_forward_stream_i16_memonly<>, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
 				else
 #endif
 				if (u8 && pl->channels == 3)
@@ -1145,7 +1145,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 						return rc;
 #ifdef AKO_MEASURE
 					if (pl->tune.dbg & 16)
-						hipLaunchKernelGGL(k_inverse_stream_u8_memonly, dim3((uint32_t)blocks), dim3(128 * (uint32_t)pl->tune.inv_pairs), 0, pl->stream, P, G);
+						hipLaunchKernelGGL(k_inverse_stream_u8_memonly<>, dim3((uint32_t)blocks), dim3(128 * (uint32_t)pl->tune.inv_pairs), 0, pl->stream, P, G);
 					else
 #endif
 						launch_inverse_u8(pl, true, L.kind, P, G, (uint32_t)blocks);

@@ -1375,6 +1375,7 @@ constexpr int U8_RING = AKO_U8_RING;  // row slots the u8 forward kernel fetches
 // reads AKO_HIP_DBG.
 #ifdef AKO_MEASURE
 // measurement aid: the interior body's loads and stores without its arithmetic, every unit (AKO_HIP_DBG bit 4)
+template <int UNUSED = 0>  // (a template: every translation unit of a measurement build may hold it)
 __global__ __launch_bounds__(THREADS) void k_forward_stream_u8_memonly(const LevelParams P, const StreamGeom G)
 {
 	const UnitId id = decode_unit(P, G);
@@ -1385,6 +1386,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream_u8_memonly(const Lev
 	forward_stream_body<K_DD137, 2, true, false, false, true, 0, true, 2, U8_RING, true>(P, G, id, lc, lane);
 }
 
+template <int UNUSED = 0>  // (a template: every translation unit of a measurement build may hold it)
 __global__ __launch_bounds__(THREADS) void k_forward_stream_i16_memonly(const LevelParams P, const StreamGeom G)
 {
 	const UnitId id = decode_unit(P, G);
@@ -1899,6 +1901,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 
 #ifdef AKO_MEASURE
 // measurement aid (AKO_HIP_DBG bit 4): the u8 inverse level kernel's loads and stores alone
+template <int UNUSED = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_inverse_stream_u8_memonly(const LevelParams P, const StreamGeom G)
 {
 	const UnitId id = decode_unit(P, G);

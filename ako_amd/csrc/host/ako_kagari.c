@@ -137,6 +137,9 @@ struct bit_source
 	const uint8_t* at;
 	const uint8_t* end;
 	const uint8_t* base;
+	int saw_long; /* codes of more than 31 bits that came by (no int16 value has one): damaged input.  Whether such a code fits
+	               * what is 'held' depends on the refill history, which a parser that joined the stream halfway does not
+	               * share with the sequential reader -- the parallel tokenizer hands such blocks back */
 };
 
 /* Next gamma code, low 16 bits (kagari.c keeps it in a uint16_t, so an over-long code simply wraps).
@@ -167,6 +170,8 @@ static inline int source_get(struct bit_source* s, uint16_t* value)
 	const uint32_t top = (uint32_t)(s->acc >> 32);
 	const int zeros = top ? __builtin_clz(top) : 32;
 	const int bits = 2 * zeros + 1;
+	if (bits > 31)
+		s->saw_long++;
 	if (bits > s->held)
 		return 0;
 	*value = (uint16_t)(s->acc >> (64 - bits));
@@ -187,7 +192,7 @@ size_t akoHostKagariDecode(size_t values_no, size_t input_bytes, size_t output_b
 	if (values_no > output_bytes / 2)
 		return 0;
 
-	struct bit_source s = {0, 0, input, (const uint8_t*)input + input_bytes, input};
+	struct bit_source s = {0, 0, input, (const uint8_t*)input + input_bytes, input, 0};
 	int16_t* out = output;
 	size_t done = 0;
 	int16_t prev = 0;
@@ -291,6 +296,7 @@ struct pt_mark
 	int32_t prev;
 	uint32_t same;
 	size_t n_lit, n_runs;
+	int long_codes; /* over-long codes seen so far (bit_source.saw_long) */
 };
 
 struct pt_sync
@@ -317,6 +323,7 @@ struct pt_worker
 	struct pt_mark* marks;
 	size_t n_marks;
 	uint64_t last_skip_bit; /* speculative phase only: end of the last stretch that could not be a code */
+	int trail_failed;       /* ... its last step failed with no byte left to restart on */
 	/* outcome */
 	int ok;
 	size_t join_mark;  /* index into right->marks where this worker stopped */
@@ -398,6 +405,8 @@ static int pt_meet(struct pt_sync* y)
 static void pt_parse(struct pt_worker* w)
 {
 	w->ok = 0;
+	if (w->trail_failed)
+		return;
 	const uint64_t end_bit_of_range = (uint64_t)w->end * 8;
 	for (;;)
 	{
@@ -467,13 +476,21 @@ static void* pt_main(void* arg)
 		{
 			struct pt_mark* m = &w->marks[w->n_marks++];
 			m->bit = pt_bit(&w->s), m->done = w->done, m->prev = w->prev, m->same = w->same;
-			m->n_lit = w->tok.n_literals, m->n_runs = w->tok.n_runs;
-			if (pt_step(w) > 0)
+			m->n_lit = w->tok.n_literals, m->n_runs = w->tok.n_runs, m->long_codes = w->s.saw_long;
+			const int r = pt_step(w);
+			if (r > 0)
 				continue;
 			const size_t next_byte = (size_t)(m->bit / 8) + 1;
 			if (next_byte >= w->input_bytes)
+			{
+				/* r == 0: the block ran out, the ordinary end of the last range.  r < 0: a code BROKE in the block's last
+				 * byte (a third equal value whose run code is missing) and nothing is left to restart on -- the
+				 * sequential reader calls such a block broken, and that verdict is not ours to give */
+				if (r < 0)
+					w->trail_failed = 1;
 				break;
-			const struct bit_source restart = {0, 0, w->input + next_byte, w->input + w->input_bytes, w->input};
+			}
+			const struct bit_source restart = {0, 0, w->input + next_byte, w->input + w->input_bytes, w->input, 0};
 			w->s = restart;
 			w->prev = PT_UNKNOWN, w->same = 0;
 			w->last_skip_bit = (uint64_t)next_byte * 8;
@@ -538,7 +555,7 @@ static int tokenize_in_parallel(size_t threads, size_t values_no, size_t input_b
 		w[k].first = (k == 0);
 		w[k].input = input, w[k].input_bytes = input_bytes;
 		w[k].begin = input_bytes * k / threads, w[k].end = input_bytes * (k + 1) / threads;
-		const struct bit_source start = {0, 0, input + w[k].begin, input + input_bytes, input};
+		const struct bit_source start = {0, 0, input + w[k].begin, input + input_bytes, input, 0};
 		w[k].s = start;
 		w[k].prev = PT_UNKNOWN;
 		w[k].dst = tok, w[k].dst_lit0 = tok->n_literals;
@@ -591,7 +608,9 @@ static int tokenize_in_parallel(size_t threads, size_t values_no, size_t input_b
 		size_t lits = 0, runs = 0;
 		for (size_t k = 0; k < threads && good; k++)
 		{
-			if (!w[k].ok)
+			/* (an over-long code in what a worker KEEPS -- everything behind the mark its left neighbour joined at)
+			 * sends the block back; the speculative stretch in front of that mark is dropped anyway) */
+			if (!w[k].ok || w[k].s.saw_long != (k != 0 ? w[k].marks[w[k - 1].join_mark].long_codes : 0))
 				good = 0;
 			else
 			{
@@ -679,7 +698,7 @@ size_t akoHostKagariTokenizeWith(size_t max_threads, size_t values_no, size_t in
 			return input_bytes;
 	}
 
-	struct bit_source s = {0, 0, input, (const uint8_t*)input + input_bytes, input};
+	struct bit_source s = {0, 0, input, (const uint8_t*)input + input_bytes, input, 0};
 	size_t done = 0;
 	int16_t prev = 0;
 	unsigned same = 0;

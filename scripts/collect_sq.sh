@@ -4,7 +4,8 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/sq_${1:-full8192}
 mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --workload ${1:-full8192} --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/p1.json" 2> "$OUT/p1.err" || { tail -5 "$OUT/p1.err"; exit 1; }
+CTRS=${SQ_COUNTERS:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY}
+rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --workload ${1:-full8192} --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/p1.json" 2> "$OUT/p1.err" || { tail -5 "$OUT/p1.err"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, os
 from collections import defaultdict
@@ -26,4 +27,7 @@ for name, c in acc.items():
         w, m.get("SQ_INSTS_VALU",0)/w, m.get("SQ_INSTS_SALU",0)/w, m.get("SQ_WAVE_CYCLES",0)/w,
         m.get("SQ_WAIT_ANY",0)/max(m.get("SQ_WAVE_CYCLES",1),1), m.get("SQ_WAIT_INST_ANY",0)/max(m.get("SQ_WAVE_CYCLES",1),1),
         m.get("SQ_ACTIVE_INST_VALU",0)/max(m.get("SQ_WAVE_CYCLES",1),1), m.get("SQ_ACTIVE_INST_ANY",0)/max(m.get("SQ_WAVE_CYCLES",1),1)))
+    if "SQ_INSTS_VMEM_WR" in m or "SQ_INSTS_VMEM_RD" in m:
+        print("   VMEM reads/wave %.0f  VMEM writes/wave %.0f" % (m.get("SQ_INSTS_VMEM_RD",0)/w, m.get("SQ_INSTS_VMEM_WR",0)/w))
 PY
+rm -rf "$OUT/p1"

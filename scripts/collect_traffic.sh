@@ -10,6 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -- python3 "$R/scripts/traffic_step.py" > "$OUT/$C.json" 2> "$OUT/$C.err" || { tail -5 "$OUT/$C.err"; exit 1; }
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -- python3 "$R/scripts/traffic_step.py" "$WL" > "$OUT/$C.json" 2> "$OUT/$C.err" || { tail -5 "$OUT/$C.err"; exit 1; }
 done
 python3 "$R/scripts/parse_traffic.py" "$OUT" "$WL"
+rm -rf "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE"  # (raw per-dispatch counter files: tens of MiB; traffic_raw.json holds what was read from them)

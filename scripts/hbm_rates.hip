@@ -26,6 +26,53 @@ __global__ void k_copy(const uint4* __restrict__ in, uint4* __restrict__ out, si
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
 		out[i] = in[i];
 }
+// tuned copy: U independent 16-byte loads in flight per lane before the first store, 16-byte stores,
+// each workgroup on a contiguous chunk (no grid-stride hop between a lane's accesses: consecutive 4 KiB pieces)
+template <int U>
+__global__ void k_copy_tuned(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+	const size_t per_block = (size_t)blockDim.x * U;
+	for (size_t base = blockIdx.x * per_block; base < n; base += (size_t)gridDim.x * per_block)
+	{
+		uint4 v[U];
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const size_t i = base + (size_t)u * blockDim.x + threadIdx.x;
+			v[u] = (i < n) ? __builtin_nontemporal_load(&in[i]) : make_uint4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const size_t i = base + (size_t)u * blockDim.x + threadIdx.x;
+			if (i < n)
+				__builtin_nontemporal_store(v[u], &out[i]);
+		}
+	}
+}
+template <int U>
+__global__ void k_copy_tuned_plain(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+	const size_t per_block = (size_t)blockDim.x * U;
+	for (size_t base = blockIdx.x * per_block; base < n; base += (size_t)gridDim.x * per_block)
+	{
+		uint4 v[U];
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const size_t i = base + (size_t)u * blockDim.x + threadIdx.x;
+			v[u] = (i < n) ? in[i] : make_uint4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const size_t i = base + (size_t)u * blockDim.x + threadIdx.x;
+			if (i < n)
+				out[i] = v[u];
+		}
+	}
+}
+
 // one wave reads 1 KiB of a row, then the same 1 KiB of the next row (pitch bytes further), like a strip walk
 __global__ void k_read_strips(const uint4* __restrict__ in, uint32_t* out, size_t pitch16, int rows_per_wave, int strips)
 {
@@ -72,6 +119,19 @@ int main()
 		const double c = time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, a, b, n); });
 		printf("blocks %6d  read %7.1f GB/s  write %7.1f GB/s  copy %7.1f GB/s (read + write)\n", blocks, bytes / r / 1e6, bytes / w / 1e6,
 		       2.0 * bytes / c / 1e6);
+	}
+	for (int blocks : {1024, 2048, 4096, 16384})
+	{
+		const double c4 = time_ms([&] { hipLaunchKernelGGL(k_copy_tuned_plain<4>, dim3(blocks), dim3(256), 0, 0, a, b, n); });
+		const double c8 = time_ms([&] { hipLaunchKernelGGL(k_copy_tuned_plain<8>, dim3(blocks), dim3(256), 0, 0, a, b, n); });
+		const double n4 = time_ms([&] { hipLaunchKernelGGL(k_copy_tuned<4>, dim3(blocks), dim3(256), 0, 0, a, b, n); });
+		const double n8 = time_ms([&] { hipLaunchKernelGGL(k_copy_tuned<8>, dim3(blocks), dim3(256), 0, 0, a, b, n); });
+		printf("tuned copy, blocks %6d: 4 loads in flight %7.1f, 8 loads %7.1f; non-temporal 4 loads %7.1f, 8 loads %7.1f GB/s (read + write)\n", blocks,
+		       2.0 * bytes / c4 / 1e6, 2.0 * bytes / c8 / 1e6, 2.0 * bytes / n4 / 1e6, 2.0 * bytes / n8 / 1e6);
+	}
+	{
+		const double m = time_ms([&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); });
+		printf("hipMemcpyAsync device to device: %7.1f GB/s (read + write)\n", 2.0 * bytes / m / 1e6);
 	}
 	// strip walk: an "image" of 8192 rows x 32 KiB (256 MiB), 32 strips of 1 KiB, R rows per wave
 	for (int rows : {16, 64, 256})

@@ -387,9 +387,25 @@ def test_kagari_tokenizer_in_parallel_equals_the_sequential_parse(po):
                     assert (after[0] - before[0]) + (after[1] - before[1]) == 1, (trial, threads, size)
                     clean_parallel += after[0] - before[0]
             # damaged / mis-sized blocks: the sequential verdict, whatever the threads made of them
-            for damage in range(8):
+            for damage in range(10):
                 bad, length, values = packed[:size].copy(), size, n
-                if damage < 3:
+                if damage == 8:
+                    # the block ends in a third equal value whose run code is missing (a speculative trail that
+                    # fails in the last byte must not be accepted): same values with an equal triple at the end, the last
+                    # set bit -- the run code "1" -- cleared
+                    v3 = v.copy()
+                    v3[-3:] = 7
+                    pk3 = np.zeros(8 * n + 64, dtype=np.uint8)
+                    s3 = L.akoHostKagariEncode(n * 2, pk3.size, v3.ctypes.data_as(V), pk3.ctypes.data_as(V))
+                    bad, length = pk3[:s3].copy(), s3
+                    last = int(np.flatnonzero(bad)[-1])
+                    bad[last] &= ~np.uint8(bad[last] & -bad[last])  # lowest set bit of the last non-zero byte
+                elif damage == 9:
+                    # a code of more than 31 bits (a run of zero bytes) somewhere behind the first range: whether it still
+                    # "fits" depends on the reader's refill history, so the threads must leave the verdict to the sequential loop
+                    at = int(rng.integers(size // 3, max(size // 3 + 1, size - 6)))
+                    bad[at:at + int(rng.integers(3, 6))] = 0
+                elif damage < 3:
                     bad[int(rng.integers(0, size))] ^= 1 << int(rng.integers(0, 8))
                 elif damage == 3:
                     length = int(rng.integers(1, size + 1))
