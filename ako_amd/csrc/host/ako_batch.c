@@ -53,6 +53,7 @@ struct akoHipBatch
 	enum akoStatus* status;
 	size_t next;   /* next image index, atomically incremented */
 	size_t failed; /* images that did not make it */
+	int busy;      /* a call is in progress: the call state above, the lanes' plans and their staging belong to it */
 };
 
 static void set_status(struct akoHipBatch* b, size_t i, enum akoStatus st)
@@ -266,7 +267,12 @@ static int run_call(struct akoHipBatch* b)
 	for (size_t k = 0; k < lanes; k++)
 		any |= b->lanes[k].started;
 	if (!any && lanes != 0)
-		lane_main(&b->lanes[0]); /* no thread could be started: the caller does the work */
+	{
+		/* no thread could be started: the caller does the work (and gets its own parse-thread limit back afterwards) */
+		const size_t callers_limit = akoHostKagariThreadLimitGet();
+		lane_main(&b->lanes[0]);
+		akoHostKagariThreadLimit(callers_limit);
+	}
 	for (size_t k = 0; k < lanes; k++)
 		if (b->lanes[k].started)
 			pthread_join(b->lanes[k].thread, NULL);
@@ -369,9 +375,13 @@ AKO_API int akoHipEncodeBatch(akoHipBatch* b, size_t n_images, const void* const
 		return (int)AKO_INVALID_INPUT;
 	for (size_t i = 0; i < n_images; i++)
 		out_blobs[i] = NULL, out_sizes[i] = 0;
+	if (__atomic_exchange_n(&b->busy, 1, __ATOMIC_ACQUIRE))
+		return (int)AKO_ERROR; /* one call at a time per batch (include/ako_hip.h) */
 	b->decode = 0, b->n = n_images, b->in = images, b->in_sizes = NULL;
 	b->out = out_blobs, b->out_sizes = out_sizes, b->status = out_status;
-	return run_call(b);
+	const int rc = run_call(b);
+	__atomic_store_n(&b->busy, 0, __ATOMIC_RELEASE);
+	return rc;
 }
 
 AKO_API int akoHipDecodeBatch(akoHipBatch* b, size_t n_blobs, const void* const* blobs, const size_t* blob_sizes,
@@ -379,7 +389,11 @@ AKO_API int akoHipDecodeBatch(akoHipBatch* b, size_t n_blobs, const void* const*
 {
 	if (b == NULL || (n_blobs != 0 && (blobs == NULL || blob_sizes == NULL || images == NULL)))
 		return (int)AKO_INVALID_INPUT;
+	if (__atomic_exchange_n(&b->busy, 1, __ATOMIC_ACQUIRE))
+		return (int)AKO_ERROR; /* one call at a time per batch (include/ako_hip.h) */
 	b->decode = 1, b->n = n_blobs, b->in = blobs, b->in_sizes = blob_sizes;
 	b->out = images, b->out_sizes = NULL, b->status = out_status;
-	return run_call(b);
+	const int rc = run_call(b);
+	__atomic_store_n(&b->busy, 0, __ATOMIC_RELEASE);
+	return rc;
 }

@@ -94,10 +94,11 @@ struct plan_slots
 	 * megabytes whose pages cost more to hand back and fault in again than the parse that fills them */
 	struct akoKagariTokens spare;
 };
-#define SPARE_TOKENS_MAX ((size_t)1 << 30) /* bytes of list capacity worth keeping */
+#define SPARE_TOKENS_MAX ((size_t)256 << 20) /* bytes of list capacity a thread keeps for its next call (an 8192 x 8192 RGBA
+                                              * stream's lists are ~150 MB; bigger ones are given back: ADVICE r2) */
 
 #define POOL_PLANS 8
-#define DOOMED_PLANS 64
+#define DOOMED_CHUNK 64
 static pthread_mutex_t pool_mutex = PTHREAD_MUTEX_INITIALIZER;
 static struct
 {
@@ -105,8 +106,8 @@ static struct
 	struct plan_key key;
 	int slot;
 } pool[POOL_PLANS];
-static akoHipPlan* doomed[DOOMED_PLANS];
-static size_t n_doomed = 0;
+static akoHipPlan** doomed = NULL; /* grows on demand: a plan that cannot be parked is NEVER dropped (each holds device memory) */
+static size_t n_doomed = 0, cap_doomed = 0;
 
 static pthread_key_t slots_key;
 static pthread_once_t slots_once = PTHREAD_ONCE_INIT;
@@ -130,9 +131,18 @@ static void slots_park(void* arg)
 				pool[e].plan = sl->plans[k], pool[e].key = sl->keys[k], pool[e].slot = k;
 				placed = 1;
 			}
-		if (!placed && n_doomed < DOOMED_PLANS)
-			doomed[n_doomed++] = sl->plans[k], placed = 1;
-		/* (both full: the plan is lost to the process -- 72 parked plans mean nobody is coming back for them) */
+		if (!placed)
+		{
+			if (n_doomed == cap_doomed)
+			{
+				akoHipPlan** grown = realloc(doomed, (cap_doomed + DOOMED_CHUNK) * sizeof *doomed); /* (no HIP call) */
+				if (grown != NULL)
+					doomed = grown, cap_doomed += DOOMED_CHUNK;
+			}
+			if (n_doomed < cap_doomed)
+				doomed[n_doomed++] = sl->plans[k], placed = 1;
+			/* (only a failed realloc of a few hundred bytes loses the plan to the process) */
+		}
 	}
 	pthread_mutex_unlock(&pool_mutex);
 	akoHostKagariTokensFree(&sl->spare);
@@ -168,15 +178,14 @@ static void reap_doomed(void)
 {
 	if (__atomic_load_n(&n_doomed, __ATOMIC_RELAXED) == 0)
 		return;
-	akoHipPlan* mine[DOOMED_PLANS];
-	size_t n;
 	pthread_mutex_lock(&pool_mutex);
-	n = n_doomed;
-	memcpy(mine, doomed, n * sizeof mine[0]);
-	n_doomed = 0;
+	akoHipPlan** mine = doomed;
+	const size_t n = n_doomed;
+	doomed = NULL, n_doomed = 0, cap_doomed = 0;
 	pthread_mutex_unlock(&pool_mutex);
 	for (size_t k = 0; k < n; k++)
 		akoHipPlanDestroy(mine[k]);
+	free(mine);
 }
 
 static akoHipPlan* pool_take(int slot, const struct plan_key* key)

@@ -53,6 +53,7 @@ AKO_API void akoHostKagariParallelStats(size_t* accepted, size_t* handed_back);
 AKO_API size_t akoHostKagariTokenizeWith(size_t max_threads, size_t values_no, size_t input_bytes, const void* input,
                                          uint64_t out_base, struct akoKagariTokens* tok);
 AKO_API void akoHostKagariThreadLimit(size_t max_threads); /* for the calling thread; 0 = no limit */
+AKO_API size_t akoHostKagariThreadLimitGet(void);            /* the calling thread's current limit */
 AKO_API int akoHostKagariTokensReserve(struct akoKagariTokens* tok, size_t literals, size_t runs); /* room for that many MORE */
 AKO_API int akoHostKagariTokensAppend(struct akoKagariTokens* dst, const struct akoKagariTokens* src,
                                       uint32_t literal_base);

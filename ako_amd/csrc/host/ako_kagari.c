@@ -677,6 +677,10 @@ void akoHostKagariThreadLimit(size_t max_threads)
 {
 	thread_limit = max_threads;
 }
+size_t akoHostKagariThreadLimitGet(void)
+{
+	return thread_limit;
+}
 
 /* max_threads: 0 = as many as pay (pt_threads) within the calling thread's limit, 1 = the sequential loop only */
 size_t akoHostKagariTokenizeWith(size_t max_threads, size_t values_no, size_t input_bytes, const void* input,

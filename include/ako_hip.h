@@ -166,7 +166,14 @@ int akoHipDecodeDownload(akoHipPlan*, void* h_images);
  * akoEncodeRatioExt     the whole search of tools/akoenc.cpp:112-217 behind one call: same bracketing and bisection,
  *                       same chosen quantization and same blob as repeated akoEncodeExt calls, with one upload and
  *                       one transform per distinct colour transformation (at most two).  *out_quantization: the
- *                       factor it settled on; *out_encodes: how many candidate encodes it replaced */
+ *                       factor it settled on; *out_encodes: how many candidate encodes it replaced.
+ *                       Where it differs from calling akoEncodeExt in that loop: (1) the callbacks' EVENTS are not
+ *                       fired during the search (the candidates are not per-tile encode passes; the reference tool
+ *                       does not install its events callback for a ratio search either: tools/akoenc.cpp:271-277) --
+ *                       allocation callbacks are honoured; (2) ratio <= 1 is a single lossless encode (the tool's
+ *                       "ratio == 1" rule, tools/akoenc.cpp:118-126, extended to 0 and negatives instead of
+ *                       dividing by them); (3) the bracket stops growing at quantization 2^28 (the tool's loop
+ *                       would overflow its int there) */
 int akoHipRequantize(akoHipPlan*, int quantization, int gate, const void* d_unquantized, void** d_out);
 void* akoHipPlanDeviceImages(akoHipPlan*);
 void* akoHipPlanDeviceStreams(akoHipPlan*);
@@ -195,7 +202,10 @@ void akoHipThreadRelease(void);
  *                     (out_status may be NULL).  Returns 0 when every image was encoded
  * akoHipDecodeBatch   blobs of images of the batch's shape -> images[i] (caller's buffers of image bytes each)
  * Images in pinned memory (akoHipHostAlloc) are copied to / from the device directly; pageable ones go through the
- * lane's pinned staging (one pass of a lane thread over the pixels). */
+ * lane's pinned staging (one pass of a lane thread over the pixels).
+ * ONE call at a time per batch object: the call's state, the lanes' plans and their staging belong to the call in
+ * progress; a second thread that calls akoHipEncodeBatch / akoHipDecodeBatch on the same batch meanwhile gets AKO_ERROR
+ * (several batch objects may of course be used side by side). */
 typedef struct akoHipBatch akoHipBatch;
 akoHipBatch* akoHipBatchCreate(const int* devices, size_t n_devices, size_t lanes_per_device,
                                const struct akoSettings* settings, size_t channels, size_t image_w, size_t image_h,

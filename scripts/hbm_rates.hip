@@ -28,18 +28,21 @@ __global__ void k_copy(const uint4* __restrict__ in, uint4* __restrict__ out, si
 }
 // tuned copy: U independent 16-byte loads in flight per lane before the first store, 16-byte stores,
 // each workgroup on a contiguous chunk (no grid-stride hop between a lane's accesses: consecutive 4 KiB pieces)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int U>
-__global__ void k_copy_tuned(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+__global__ void k_copy_tuned(const uint4* __restrict__ in4, uint4* __restrict__ out4, size_t n)
 {
+	const u32x4* in = reinterpret_cast<const u32x4*>(in4);
+	u32x4* out = reinterpret_cast<u32x4*>(out4);
 	const size_t per_block = (size_t)blockDim.x * U;
 	for (size_t base = blockIdx.x * per_block; base < n; base += (size_t)gridDim.x * per_block)
 	{
-		uint4 v[U];
+		u32x4 v[U];
 #pragma unroll
 		for (int u = 0; u < U; u++)
 		{
 			const size_t i = base + (size_t)u * blockDim.x + threadIdx.x;
-			v[u] = (i < n) ? __builtin_nontemporal_load(&in[i]) : make_uint4(0, 0, 0, 0);
+			v[u] = (i < n) ? __builtin_nontemporal_load(&in[i]) : u32x4{0, 0, 0, 0};
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++)
