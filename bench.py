@@ -472,6 +472,9 @@ def main():
         kern_ms = sum(a["ms"] for a in agg.values()) / args.steps
         total_alg_bytes = (3 * ch * pixels * 2) if not planes else (8 * pixels)
         copy_gbps = copy_bandwidth(torch, dev)
+        api.lib().akoHipTunedCopyGBps.restype = C.c_double
+        api.lib().akoHipTunedCopyGBps.argtypes = [C.c_size_t, C.c_int]
+        tuned_gbps = float(api.lib().akoHipTunedCopyGBps(1 << 30, 10))
         traffic_bytes, traffic_src = measured_traffic(args.workload, dom_key[0], dom_key[1])
         out = {
             "metric": "Mpixels/s encode+decode (DD137, q=16)",
@@ -511,15 +514,18 @@ def main():
                 "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": dom["bytes"],
-                "measured_copy_GBps": round(copy_gbps, 1),
-                "frac_of_measured_copy": round(achieved / copy_gbps, 4),
+                "measured_copy_GBps": round(max(copy_gbps, tuned_gbps), 1),
+                "frac_of_measured_copy": round(achieved / max(copy_gbps, tuned_gbps), 4),
+                "copy_kernels_GBps": {"tuned (4 x 16 B in flight per lane, non-temporal; libako akoHipTunedCopyGBps)": round(tuned_gbps, 1),
+                                      "torch tensor copy": round(copy_gbps, 1)},
                 "note": ("kernel durations: HIP events on the kernel's own stream inside bench.py. With several steps in "
                          "flight the kernels of different steps share the chip, so 'achieved' is taken from the passes "
                          "bench.py runs with ONE step in flight right after the timed region (same plan, same buffers; "
                          "profiles/*_inflight1_kernel_stats.csv is rocprofv3 --kernel-trace --stats of that mode); "
                          "'timed_region' is the same kernel in the overlapped regime: the K steps repeated, untimed, with "
                          "events around every launch (the timed regions themselves carry no events: they cost about 8 % "
-                         "of the overlapped throughput); measured_copy_GBps = read + write rate of a 1 GiB device copy"),
+                         "of the overlapped throughput); measured_copy_GBps = read + write rate of a 1 GiB device copy, the "
+                         "faster of the two copy kernels"),
                 "timed_region": {"steps_in_flight": nfl, "avg_launch_ms": round(timed_ms, 4),
                                  "achieved": round(dom["bytes"] / (timed_ms * 1e-3) / 1e9, 1),
                                  "frac": round(dom["bytes"] / (timed_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},

@@ -222,6 +222,10 @@ void* akoHipHostAlloc(size_t bytes);
 void akoHipHostFree(void* p);
 int akoHipHostIsPinned(const void* p); /* 1: page-locked memory the HIP runtime knows (akoHipHostAlloc, hipHostRegister) */
 
+/* measurement aid: read + write GB/s of a tuned device-to-device copy of `bytes` on the current device (two temporary
+ * buffers of that size); the practical memory rate bench.py reports beside the 8 TB/s spec peak.  0 on failure. */
+double akoHipTunedCopyGBps(size_t bytes, int repeats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,19 @@ __global__ __launch_bounds__(256) void k_walk_rw(const uint8_t* __restrict__ img
 				const u32x4 v = pl ? b : a;
 				if (SHAPE == 1 && lane >= 60)
 					continue;
+				if (SHAPE == 3)
+				{
+					// what an LDS exchange inside a two-strip workgroup would give: the wave of the even strip stores sub-bands
+					// 0, 1 of BOTH strips (480 contiguous bytes, 8 bytes per lane), the wave of the odd strip sub-bands 2, 3
+					if (lane < 60)
+					{
+						uint8_t* pp = out + (size_t)(2 * pl + role) * 4 * sub + r * row_b + (strip & ~1u) * 240 + (role ? 2 : 0) + lane * 8;
+						const int s0 = (strip & 1) ? 2 : 0;
+						{ const uint2 w = make_uint2(v.x, v.y); __builtin_memcpy(pp + (size_t)s0 * sub, &w, 8); }
+						{ const uint2 w = make_uint2(v.z, v.w); __builtin_memcpy(pp + (size_t)(s0 + 1) * sub, &w, 8); }
+					}
+					continue;
+				}
 				if (WIDE == 0)
 				{
 					*reinterpret_cast<uint32_t*>(plane + 0 * sub + lane * 4) = v.x;
@@ -173,5 +186,7 @@ int main()
 	run_rw<2, 0, false, 2>(img, out, "stores only, 256-byte runs on 256-byte boundaries");
 	run_rw<2, 0, true, 1>(img, out, "loads + stores, 240-byte runs (kernel)");
 	run_rw<2, 0, true, 2>(img, out, "loads + stores, aligned 256-byte runs");
+	run_rw<2, 0, false, 3>(img, out, "stores only, 480-byte runs (two strips merged)");
+	run_rw<2, 0, true, 3>(img, out, "loads + stores, 480-byte runs (two strips merged)");
 	return 0;
 }
