@@ -23,6 +23,7 @@ HIP_SOURCES = {
                      "ako_requant.hip.h", "ako_fused.h", "ako_u8.h"],
     "ako_u8_rgba.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
     "ako_u8_rgb.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
+    "ako_u8_group.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8.h"],
     "ako_fused.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_fused.h", "ako_fused.hip.h"],
 }
 C_SOURCES = ["host/ako_quant.c", "host/ako_head.c", "host/ako_misc.c", "host/ako_kagari.c", "host/ako_codec.c",

@@ -635,6 +635,7 @@ __device__ __forceinline__ void f2_inverse_body(const F2Params& P, const F2Unit&
 		}
 		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 		__builtin_amdgcn_raw_buffer_store_b128(u32x4{px[0], px[1], px[2], px[3]}, rs_img, px_lane_off, (uint32_t)(2 * r + role) * out_pitch, 0);
+		AKO_STORE_GUARD();  // (see store_b128_guarded in ako_stream.hip.h)
 	};
 
 	// Iteration i: [A] level-1 slot r1_lo - 7 + i leaves the low-pass rows of level-1 output slot m = r1_lo - 10 + i in half

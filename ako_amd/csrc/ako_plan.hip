@@ -143,6 +143,10 @@ struct Tuning
 	int fuse2 = 0;         // AKO_HIP_FUSE2: levels 0 and 1 of eligible RGBA plans in one workgroup walk, the level-0 low-pass plane
 	                       // handed over through LDS (ako_fused.hip.h): bit 0 forward, bit 1 inverse.  Bit-exact and parity-tested,
 	                       // off by default: measured slower than the level-per-kernel launches
+	int group = 0;         // AKO_HIP_GROUP: level 0 of big RGBA tiles in column groups, the stores re-shaped into whole cache lines
+	                       // (k_forward_group_u8, ako_stream.hip.h).  Bit-exact and parity-tested, off by default: the level-0
+	                       // kernels turned out to be bound by instruction issue, not by their stores
+	int group_min = 1024;  // AKO_HIP_GROUP_MIN: narrowest level-0 sub-band (columns) that takes the group kernel
 	int f2_rows = 0;       // AKO_HIP_F2_ROWS: rows per segment of those kernels (0 = one round of workgroups)
 	int f2_edge = -1;      // AKO_HIP_F2_EDGE: rows of their first / last segment (-1 = chosen, 0 = like the others)
 	uint32_t dbg = 0;      // AKO_HIP_DBG bits (kernel side experiments)
@@ -182,6 +186,8 @@ struct Tuning
 		if (t.inv_pairs != 1 && t.inv_pairs != 4)
 			t.inv_pairs = 2;
 		t.fuse2 = num("AKO_HIP_FUSE2", 0) & 3;
+		t.group = num("AKO_HIP_GROUP", 0);
+		t.group_min = num("AKO_HIP_GROUP_MIN", 1024);
 		t.f2_rows = num("AKO_HIP_F2_ROWS", 0);
 		t.f2_edge = num("AKO_HIP_F2_EDGE", -1);
 #ifdef AKO_MEASURE  // measurement builds only: the shipped library does not read AKO_HIP_DBG
@@ -460,15 +466,16 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 // segments of <= 6 rows + 6 halo slots, or of <= 2 rows
 constexpr int DEEP_SLOTS = 12, DEEP_SLOTS_SHORT = 8;
 
-StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8, bool inverse)
+// (groups != 0: the column-group kernel -- StreamGeom::strips then counts groups, waves_per_row_unit = 8 per tile instance)
+StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8, bool inverse, uint32_t groups = 0)
 {
 	StreamGeom G;
-	G.strips = (L.tw + SNET - 1) / SNET;
+	G.strips = groups ? groups : (L.tw + SNET - 1) / SNET;
 	G.wide = 0;
 	G.lockstep = (uint32_t)pl->tune.lockstep;
 	G.edge_rows = 0;
 	// 121..128 coefficient columns (an even number): one strip without halo lanes instead of two
-	if (L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && pl->tune.wide)
+	if (!groups && L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && pl->tune.wide)
 		G.strips = 1, G.wide = 1;
 	uint32_t seg_rows = (uint32_t)pl->tune.seg_rows;
 	if (pl->tune.seg_rows_big != 0 && L.tw >= 1024)  // tuning aid: levels with >= 1024 columns only
@@ -513,6 +520,16 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 	{
 		G.edge_rows = EDGE_ROWS;
 		G.segs = 3 + (L.th - 3 * EDGE_ROWS + seg_rows - 1) / seg_rows;
+		// the short border segments are extra units: keep the launch within the rounds of resident waves it was sized for
+		// (column groups, 10 per row of the 8192 x 8192 level: 103 segments = 1030 workgroups would be a third round of 6)
+		const uint64_t resident = 4096, units_per_seg = (uint64_t)G.strips * waves_per_row_unit;
+		const uint64_t rounds = ((uint64_t)((L.th + seg_rows - 1) / seg_rows) * units_per_seg + resident - 1) / resident;
+		while (groups && (uint64_t)G.segs * units_per_seg > rounds * resident && seg_rows < L.th)
+		{
+			seg_rows++;
+			G.seg_rows = seg_rows;
+			G.segs = 3 + (L.th - 3 * EDGE_ROWS + seg_rows - 1) / seg_rows;
+		}
 	}
 	return G;
 }
@@ -669,7 +686,21 @@ uint64_t scratch_plane_elems(const Group& g, int which)
 {
 	if ((int)g.levels.size() <= which)
 		return 0;
-	return (uint64_t)g.levels[which].tw * g.levels[which].th;
+	// a multiple of a cache line, with room for the phase shift of the column-group kernel (plane p starts up to 66 values in)
+	return ((uint64_t)g.levels[which].tw * g.levels[which].th + 128 + 63) & ~(uint64_t)63;
+}
+
+// Level 0 of a u8 RGBA plan in column groups (k_forward_group_u8, ako_stream.hip.h: "Column groups"): big tiles whose
+// sub-band width is a multiple of a cache line of values, an even level width, and a level 1 that runs on the int16
+// streaming kernel (which reads the phase-shifted low-pass planes).
+bool group_eligible(const akoHipPlan* pl, const Group& g, bool u8_level0, size_t lt)
+{
+	if (!pl->tune.group || !u8_level0 || pl->channels != 4 || g.levels.size() < 2 || lt < 2)
+		return false;
+	const LevelGeom &L0 = g.levels[0], &L1 = g.levels[1];
+	if ((L0.tw % 64) != 0 || L0.cw != 2 * L0.tw || L0.tw < (uint32_t)pl->tune.group_min || L0.kind == K_HAAR)
+		return false;
+	return stream_eligible(pl, L0, true) && stream_eligible(pl, L1, false);
 }
 
 // The in-LDS tail (window engine, ako_tail.hip.h): AKO_HIP_TAIL=0 switches it off.  (Two other engines were built and
@@ -911,6 +942,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				l = 1;  // level 1 is done
 				continue;
 			}
+			const bool grouped0 = !planes && !staged && group_eligible(pl, g, true, lt) && !fused2_eligible(pl, g, true, lt, 1);
 			if (u8)
 			{
 				P.img = (uint8_t*)d_images;
@@ -934,6 +966,8 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					P.src_pitch = L.cw;
 					P.src_plane_stride = scratch_plane_elems(g, which);
 					P.src_inst_stride = P.src_plane_stride * pl->channels;
+					if (l == 1 && grouped0)  // low-pass planes shifted to the phase of the stream's cache lines
+						P.src_tiled = 2u | ((uint32_t)((g.levels[0].grp_off[0] + 1) & 63) << 8);
 				}
 			}
 			P.plane_groups = (uint32_t)((pl->channels + P.planes_per_wg - 1) / P.planes_per_wg);
@@ -955,10 +989,12 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
-				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8, false);
+				const bool grouped = u8 && grouped0;
+				const StreamGeom G = grouped ? stream_geometry(pl, L, (uint64_t)GRP_WAVES * insts, u8, false, group_count(L.tw))
+				                             : stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8, false);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
 				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.fwd_pairs : (uint32_t)(THREADS / 64);
-				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
+				const uint64_t blocks = grouped ? (uint64_t)G.strips * G.segs * insts : (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
 					return rc;
 				// int16 narrowing after every step is a no-op where the worst-case growth of u8-sourced
@@ -975,7 +1011,9 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					hipLaunchKernelGGL(k_forward_stream_i16_memonly<>, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
 				else
 #endif
-				if (u8 && pl->channels == 3)
+				if (grouped)
+					akoLaunchForwardGroupU8_rgba(L.kind, P, G, (uint32_t)blocks, pl->stream);
+				else if (u8 && pl->channels == 3)
 					akoLaunchForwardU8_rgb(L.kind, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
 				else if (u8)
 					akoLaunchForwardU8_rgba(L.kind, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
@@ -985,7 +1023,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					launch_forward_stream<1, false, DEEP_SLOTS>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else
 					launch_forward_stream<1, false, 0>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
-				snprintf(name, sizeof name, "fwd_stream_%s%s%s", kind_name(L.kind), u8 ? "_u8" : "", deep ? "_deep" : "");
+				snprintf(name, sizeof name, "fwd_%s_%s%s%s", grouped ? "group" : "stream", kind_name(L.kind), u8 ? "_u8" : "", deep ? "_deep" : "");
 			}
 			else
 			{
@@ -1239,7 +1277,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.group, t.group_min, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;

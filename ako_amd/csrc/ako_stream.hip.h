@@ -970,6 +970,149 @@ __device__ __forceinline__ void color_inverse_fast(int color, float v0, float v1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column groups (round 3): the level-0 stores of big tiles re-shaped into whole cache lines.
+//
+// The stream format puts a one-value head in front of every plane's sub-bands (misc.c:245-285), so sub-band rows start
+// at arbitrary 2-byte offsets and a strip's 240-byte runs cut cache lines at both ends.  The memory system takes a store
+// that fills whole 128-byte lines at about twice the rate of one that leaves lines partly written (0.10 against 0.20 ms
+// for the 537 MB of the 8192 x 8192 level; a 64-byte shift already costs half of that: scripts/store_align.hip,
+// profiles/r3_store_alignment.txt).  So: a workgroup is 8 waves = 4 neighbouring strips x the pair of waves; it OWNS, in
+// every row of every sub-band of plane p, the 7 cache lines (448 columns) starting at column S - p, where S is chosen per
+// (image, tile) from the actual address of the plane-0 sub-bands; the planes' heads shift their lines by one column each,
+// which the 480 net columns of four strips cover (451 needed).  Every row slot each wave leaves its 2 x 4 packed words
+// per lane in an LDS row buffer (16 row kinds = 4 planes x LL C B D), the workgroup meets at one barrier (double buffer),
+// and wave w then stores row kinds 2 w, 2 w + 1 with one 16-byte-per-lane store each: 56 lanes = 7 whole lines.  Lines cut
+// by the tile's left / right border are stored value by value (first and last group only).  The low-pass planes in the
+// scratch buffer are shifted by the same phase (plane p by phase + p values), so that their lines coincide with the
+// stream's; the level-1 kernel reads them with the same shift (LevelParams::src_tiled).
+// Needs: sub-band width a multiple of 64 (every row and all three sub-bands of a plane then share the phase) and an even
+// level width.  A group nets 448 of 480 columns, i.e. 7 % more strips than the plain kernel walks.
+// ---------------------------------------------------------------------------------------------
+constexpr int GRP_STRIPS = 4, GRP_WAVES = 2 * GRP_STRIPS;
+constexpr int GRP_OWN = 448;  // columns a workgroup owns per row: 7 lines of int16
+constexpr int GRP_PAD = 8;    // values in front of / behind them in a row buffer (pairs cut by the ownership border land there)
+constexpr int GRP_ROW = GRP_OWN + 2 * GRP_PAD;
+constexpr int GRP_KINDS = 16;  // row kinds: plane * 4 + (0 LL, 1 C, 2 B, 3 D)
+constexpr int GRP_LDS_VALUES = 2 * GRP_KINDS * GRP_ROW;
+
+__host__ __device__ __forceinline__ uint32_t group_count(uint32_t Tc)
+{
+	return (Tc + 67u + (uint32_t)GRP_OWN - 1u) / (uint32_t)GRP_OWN;  // whatever the phase, plane 3 of the last group reaches Tc
+}
+
+// position of plane 0's sub-band rows inside a cache line, in values (plane p: + p); konst = grp_off[0] + 1 of level 0
+__device__ __forceinline__ uint32_t stream_phase(const LevelParams& P, uint32_t image, const TileDesc& td, uint32_t konst)
+{
+	return ((uint32_t)(reinterpret_cast<uintptr_t>(P.stream) >> 1) + image * (uint32_t)P.stream_stride + (uint32_t)td.stream_off + konst) & 63u;
+}
+
+// A 16-byte-per-lane buffer store followed at once by a VALU write of one of its data registers stores the NEW value in
+// part of the lanes on gfx950 (seen on the box: the next instruction's address computation showing up in the stream, four
+// lanes in sixteen).  The compiler's hazard table only knows this for stores without a scalar offset; ours always have
+// one.  Two wait states behind every such store.
+#define AKO_STORE_GUARD()                      \
+	do                                         \
+	{                                          \
+		__builtin_amdgcn_sched_barrier(0);     \
+		asm volatile("s_nop 1");               \
+		__builtin_amdgcn_sched_barrier(0);     \
+	} while (0)
+__device__ __forceinline__ void store_b128_guarded(__attribute__((ext_vector_type(4))) uint32_t v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, int aux = 0)
+{
+	__builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+	AKO_STORE_GUARD();
+	(void)aux;
+}
+
+struct __attribute__((packed, aligned(2))) U32A2
+{
+	uint32_t v;
+};
+// A packed pair into a row buffer.  The position is only 2-byte aligned when the plane's phase is odd (wave-uniform), and
+// the compiler must then be kept from fusing the halves back into ds_write_b32 / ds_write2_b32, which want a dword
+// address (seen on the box: dwords landing 2 bytes off): volatile halves.
+template <bool ODD>
+__device__ __forceinline__ void grp_put(uint8_t* at, uint32_t w)
+{
+	typedef __attribute__((address_space(3))) volatile uint16_t lds_vu16;
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	if constexpr (ODD)
+	{
+		lds_vu16* h = (lds_vu16*)at;
+		h[0] = (uint16_t)w;
+		h[1] = (uint16_t)(w >> 16);
+	}
+	else
+		*(lds_u32*)at = w;
+}
+
+// Register budget: the u8 kernels live on exactly 128 VGPRs, and a single spilled address register costs a scratch reload
+// + s_waitcnt vmcnt(0) per row slot, i.e. the prefetch.  Every per-lane address of the group kernel is therefore derived
+// from ONE register, lane16 = 16 * lane: the pixel load offset (16 bytes per lane; interior strips), the position of the
+// lane's packed words in a row buffer (4 * lane + a wave constant) and the lane's share of the drain (16 bytes per lane).
+struct GroupCtx
+{
+	int16_t* lds;
+	int S;        // first owned column of plane 0
+	// this wave's share of the stores: row kinds 2 * wave, 2 * wave + 1 (plane wave / 2: LL and C, or B and D); resources
+	// based at the plane's first owned column of row 0 (which lies in front of the sub-band in group 0)
+	__amdgpu_buffer_rsrc_t rs[2];
+	uint32_t soff[2];     // byte offset of the sub-band
+	uint32_t pitch_b[2];  // bytes per row
+	uint32_t lds_k;       // byte offset of the first owned column in row kind 2 * wave of buffer 0
+	int d_first;          // first owned column of the plane
+	bool ragged;          // the owned range crosses column 0 or Tc (first / last group): lanes are checked one by one
+	bool exists;          // (RGB: plane 3 does not)
+};
+
+// row_ok false: the same instructions with every store out of range (the slots in front of / behind a segment) -- a
+// branch around them would make the compiler's count of memory operations in flight inexact, and the wait in front of a
+// slot's pixels would then cover the NEXT slot's prefetch as well (stores count in vmcnt on gfx950).
+__device__ __forceinline__ void group_drain(const GroupCtx& gc, uint32_t lane16, int buf, int r, bool row_ok, int Tc)
+{
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	constexpr uint32_t OOB = 0xFFFFFFFFu;
+	if (!gc.exists)
+		return;
+	// 56 lanes x 16 bytes = the 7 owned lines; lanes 56..63 double lane 55 (same values, same address: cheaper than a mask)
+	const uint32_t da = min(lane16, (uint32_t)(GRP_OWN / 8 - 1) * 16u);
+	const uint8_t* rows = reinterpret_cast<const uint8_t*>(gc.lds) + gc.lds_k + (uint32_t)(buf * GRP_KINDS * GRP_ROW * 2);
+#pragma unroll
+	for (int i = 0; i < 2; i++)
+	{
+		const uint8_t* row = rows + i * GRP_ROW * 2;
+		const u32x4 v = *reinterpret_cast<const u32x4*>(row + da);
+		const uint32_t so = row_ok ? gc.soff[i] + (uint32_t)r * gc.pitch_b[i] : OOB;
+		if (!gc.ragged)  // wave-uniform
+			store_b128_guarded(v, gc.rs[i], da, so);
+		else
+		{
+			// first / last group of a row: whole lanes inside the level as above, the columns of the lanes the border cuts
+			// one by one (lanes 0..7: the columns in front of the first whole lane; lanes 8..15: the ones behind the last)
+			const int first = gc.d_first;
+			const int c = first + (int)(da >> 1);
+			store_b128_guarded(v, gc.rs[i], (c >= 0 && c + 8 <= Tc) ? da : OOB, so);
+			const int lane = (int)(lane16 >> 4);
+			int col = -1;
+			if (lane < 8)
+			{
+				const int cf = (first < 0) ? ((8 - ((-first) & 7)) & 7) : 0;
+				if (lane < cf)
+					col = lane;
+			}
+			else if (lane < 16 && first < Tc && first + GRP_OWN > Tc)
+			{
+				const int ce = Tc - ((Tc - first) & 7);
+				if (ce + lane - 8 < Tc)
+					col = ce + lane - 8;
+			}
+			const int at = (col >= 0) ? (col - first) * 2 : 0;
+			__builtin_amdgcn_raw_buffer_store_b16(*reinterpret_cast<const int16_t*>(row + at), gc.rs[i], (col >= 0) ? (uint32_t)at : OOB, so, 0);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forward.  NPL = planes handled by one wave: 2 with U8 (half of an RGBA pixel), 1 on int16 planes.
 // ---------------------------------------------------------------------------------------------
 
@@ -993,11 +1136,12 @@ struct FwdRaw<false>
 // loads in flight at once the segment costs one round trip.  (A single pass over exactly N slots: the ring indices
 // of the column pipeline stay compile-time constants for any N.)
 template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE, int DEEP, bool CFAST = false, int PF = 2, int LATE = 0,
-          bool MEMONLY = false, int CH = 4>
+          bool MEMONLY = false, int CH = 4, bool GRP = false>
 __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
-                                                    const LaneCols& lc, int lane)
+                                                    const LaneCols& lc, int lane, const GroupCtx* gcp = nullptr)
 {
 	static_assert(CH == 4 || (CH == 3 && U8 && NPL == 2), "CH = 3: the u8 kernels on RGB pixels");
+	static_assert(!GRP || (U8 && NPL == 2 && LATE > 0 && !MEMONLY), "column groups: the u8 kernel");
 	// CH = 3 (RGB): the pair's second wave owns planes 1 and 3, and plane 3 does not exist: it carries one plane
 	const bool one_plane = (CH == 3) && (id.pg == 1);
 	const TileDesc td = P.tiles[id.tile];
@@ -1028,9 +1172,11 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	}
 	else
 	{
-		const int16_t* src = P.src + (P.src_tiled ? (uint64_t)id.image : inst) * P.src_inst_stride + (uint64_t)p_first * P.src_plane_stride;
-		if (P.src_tiled)
+		const int16_t* src = P.src + ((P.src_tiled == 1) ? (uint64_t)id.image : inst) * P.src_inst_stride + (uint64_t)p_first * P.src_plane_stride;
+		if (P.src_tiled == 1)
 			src += (uint64_t)td.y0 * P.src_pitch + td.x0;
+		else if (P.src_tiled & 2)  // written by the column-group kernel: planes shifted to the phase of the stream's lines
+			src += stream_phase(P, id.image, td, P.src_tiled >> 8) + (uint32_t)p_first;
 		src_base = reinterpret_cast<const uint8_t*>(src);
 		row_pitch_b = P.src_pitch * 2u;
 	}
@@ -1070,6 +1216,21 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		ll_off[p] = (uint32_t)((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) * 2);
 	}
 	const uint32_t nsub_b = (uint32_t)(nsub * 2);
+	// GRP: this lane's packed words go to the workgroup's row buffers instead (planes p_first, p_first + 2: the second one
+	// sits 8 row kinds and 2 values further on); one predicate for both, whatever it lets through beyond the owned
+	// columns lands in the padding.  Addresses from lane16 alone (see GroupCtx): c0 = c_base + 2 * lane in every lane.
+	const uint32_t lane16 = (uint32_t)lane * 16u;
+	uint32_t lds_b = 0, src_a = 0;
+	bool lds_lane = false;
+	(void)lane16, (void)lds_b, (void)src_a, (void)lds_lane;
+	if constexpr (GRP)
+	{
+		const int idx0 = c0 - gcp->S + p_first;
+		lds_lane = store_lane && (idx0 >= -3) && (idx0 < GRP_OWN);
+		lds_b = (uint32_t)__builtin_amdgcn_readfirstlane((GRP_PAD + idx0 + 4 * p_first * GRP_ROW) * 2 - 4 * lane);
+		if constexpr (!HEDGE)  // no clamped / wrapped lane: the pixel offsets are 16 * lane + a wave constant
+			src_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(src_lane_off - lane16));
+	}
 
 	if (id.strip == 0 && id.seg == 0 && lane == 0)
 #pragma unroll
@@ -1102,12 +1263,21 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				raw.a[par] = RawVec{};
 				continue;
 			}
+#ifdef AKO_MEASURE
+			if (P.dbg & 8192)  // bit 13: the real arithmetic on constant pixels (no loads)
+			{
+				raw.a[par] = RawVec{};
+				continue;
+			}
+#endif
 			if constexpr (U8 && CH == 3)
 			{
 				typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 				const u32x3 t = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(rs_src, src_lane_off, row_off, AUX_FWD_PIXEL_LOAD));
 				raw.a[par] = RawVec{t.x, t.y, t.z, 0u};
 			}
+			else if constexpr (U8 && GRP && !HEDGE)
+				raw.a[par] = __builtin_bit_cast(RawVec, __builtin_amdgcn_raw_buffer_load_b128(rs_src, lane16, row_off + src_a, AUX_FWD_PIXEL_LOAD));
 			else if constexpr (U8)
 				raw.a[par] = __builtin_bit_cast(RawVec, __builtin_amdgcn_raw_buffer_load_b128(rs_src, src_lane_off, row_off, AUX_FWD_PIXEL_LOAD));
 			else
@@ -1235,8 +1405,48 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				pack_row_f(lp, hp, gf, rq, w_ll[p], w_c[p], w_b[p], w_d[p]);
 
 			}
+			if constexpr (GRP)
 			{
+				const bool row_ok = (r >= r_lo) && (r < r_hi);  // the same in every wave of the workgroup
+#ifdef AKO_MEASURE  // AKO_HIP_DBG bits 9..11: no barrier (races: timing only) / no drain / no row-buffer writes
+				const bool m_nobar = P.dbg & 512, m_nodrain = P.dbg & 1024, m_nolds = P.dbg & 2048;
+#else
+				constexpr bool m_nobar = false, m_nodrain = false, m_nolds = false;
+#endif
+				if (lds_lane && !m_nolds)
+				{
+					uint8_t* q = reinterpret_cast<uint8_t*>(gcp->lds) + ((lane16 >> 2) + lds_b) + (K & 1) * GRP_KINDS * GRP_ROW * 2;
+					auto put_rows = [&](auto odd) {
+#pragma unroll
+						for (int p = 0; p < NPL; p++)
+						{
+							grp_put<decltype(odd)::value>(q + 0 * GRP_ROW * 2, w_ll[p]);
+							grp_put<decltype(odd)::value>(q + 1 * GRP_ROW * 2, w_c[p]);
+							grp_put<decltype(odd)::value>(q + 2 * GRP_ROW * 2, w_b[p]);
+							grp_put<decltype(odd)::value>(q + 3 * GRP_ROW * 2, w_d[p]);
+							q += (8 * GRP_ROW + 2) * 2;
+						}
+					};
+					if (lds_b & 2u)  // wave-uniform: both planes of the wave sit at odd positions
+						put_rows(std::true_type{});
+					else
+						put_rows(std::false_type{});
+				}
+				// Every slot, inside the segment or not: one barrier, then this wave's share of the stores (out of range for a
+				// row outside the segment).  The other buffer is rewritten only behind the NEXT barrier, which no wave passes
+				// before every wave has finished reading this one.
+				if (!m_nobar)
+					__syncthreads();
+				if (!m_nodrain)
+					group_drain(*gcp, lane16, K & 1, r, row_ok, Tc);
+			}
+			else
+			{
+#ifdef AKO_MEASURE
+				const bool row_ok = (r >= r_lo) && (r < r_hi) && !(P.dbg & 4096);  // bit 12: every store dropped
+#else
 				const bool row_ok = (r >= r_lo) && (r < r_hi);  // wave-uniform
+#endif
 				const uint32_t rr = (uint32_t)r;
 				const uint32_t row_grp = rr * (uint32_t)Tc * 2u, row_ll = rr * ll_pitch * 2u;
 #pragma unroll
@@ -1244,6 +1454,10 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				{
 					if (one_plane && p == 1)
 						continue;
+#ifdef AKO_MEASURE
+					if (P.dbg & 16384)  // bit 14: no store instructions at all
+						continue;
+#endif
 					const uint32_t s_ll = row_ok ? ll_off[p] + row_ll : OOB;
 					const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
 					const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
@@ -1273,11 +1487,12 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		Raw ring[LATE];
 		static_for<LATE>([&](auto kc) {
 			fetch(v_begin + decltype(kc)::value, ring[decltype(kc)::value]);
-			phantom_stores();
+			if constexpr (!GRP)
+				phantom_stores();
 		});
 		for (int base = 0; base < n_slots; base += 6)
 		{
-			if (G.lockstep & 1)
+			if (!GRP && (G.lockstep & 1))  // (column groups meet at every row slot)
 				__builtin_amdgcn_s_barrier();
 			static_for<6>([&](auto kc) {
 				constexpr int K = decltype(kc)::value;
@@ -1434,6 +1649,116 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 #undef AKO_FWD_U8
 }
 
+// The u8 level kernel in column groups (see "Column groups" above).  StreamGeom::strips holds the number of GROUPS;
+// grid = groups x segments x tile instances workgroups of 8 waves.
+template <int KIND, int CH = 4>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_forward_group_u8(const LevelParams P, const StreamGeom G)
+{
+	__shared__ __attribute__((aligned(16))) int16_t rowbuf[GRP_LDS_VALUES];
+	// XCD-aware order as in decode_unit(): neighbouring groups / segments meet in one L2
+	uint32_t blk = blockIdx.x;
+	const uint32_t per_xcd = gridDim.x >> 3;
+	if (blk < (per_xcd << 3))
+		blk = (blk & 7) * per_xcd + (blk >> 3);
+	const uint32_t group = blk % G.strips;
+	blk /= G.strips;
+	UnitId id;
+	id.seg = blk % G.segs;
+	blk /= G.segs;
+	id.tile = blk % P.n_tiles;
+	id.image = blk / P.n_tiles;
+	id.valid = true;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int lane = threadIdx.x & 63;
+	const int strip = wave >> 1;
+	id.pg = (uint32_t)((wave & 1) ^ ((wave >> 2) & 1));  // both roles on every SIMD (wave w runs on SIMD w % 4)
+	id.strip = group * GRP_STRIPS + (uint32_t)strip;
+	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
+	const TileDesc td = P.tiles[id.tile];
+	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
+
+	const uint32_t phase = stream_phase(P, id.image, td, (uint32_t)P.grp_off[0] + 1u);
+	GroupCtx gc;
+	gc.lds = rowbuf;
+	gc.S = (int)group * GRP_OWN + (int)((64u - phase) & 63u) - 64;
+	const int c_base = ((gc.S - 8) & ~1) + strip * SNET;  // lane 0 of the strip (net from lane 2: the group nets S - 4 .. S + 475 at least)
+	const bool active = c_base + SORG < Tc;
+	const LaneCols lc = lane_columns_at(c_base, 2, 62, lane, Tc, P.wrap);
+
+	// this wave's share of the stores
+	{
+		constexpr int RSRC_FLAGS = 0x00020000;
+		const int dp = wave >> 1;
+		gc.exists = dp < CH;
+		gc.d_first = gc.S - dp;
+		int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+		int16_t* sub = tile_stream + (int64_t)(P.grp_off[gc.exists ? dp : 0] + 1) + gc.d_first;
+		int16_t* ll = P.dst + inst * P.dst_inst_stride + (uint64_t)dp * P.dst_plane_stride + phase + (uint32_t)dp + gc.d_first;
+		const uint32_t nsub_b = (uint32_t)((uint64_t)Tc * Tr * 2);
+		// (the streaming kernels' tiles stay below 0xFFF00000 bytes: every real offset is in range, and 0xFFFFFFFF + any
+		// lane offset is not)
+		constexpr int DRAIN_RANGE = (int)0xFFF00000u;
+		const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(sub, 0, DRAIN_RANGE, RSRC_FLAGS);
+		if (wave & 1)  // B and D
+		{
+			gc.rs[0] = rs_stream, gc.rs[1] = rs_stream;
+			gc.soff[0] = nsub_b, gc.soff[1] = 2u * nsub_b;
+			gc.pitch_b[0] = gc.pitch_b[1] = (uint32_t)Tc * 2u;
+		}
+		else  // LL (plane p shifted by phase + p values: its lines coincide with the stream's) and C
+		{
+			gc.rs[0] = __builtin_amdgcn_make_buffer_rsrc(ll, 0, DRAIN_RANGE, RSRC_FLAGS), gc.rs[1] = rs_stream;
+			gc.soff[0] = 0, gc.soff[1] = 0;
+			gc.pitch_b[0] = P.dst_pitch * 2u, gc.pitch_b[1] = (uint32_t)Tc * 2u;
+		}
+		gc.lds_k = (uint32_t)((2 * wave * GRP_ROW + GRP_PAD) * 2);
+		gc.ragged = (gc.d_first < 0) || (gc.d_first + GRP_OWN > Tc);
+	}
+
+	if (!active)
+	{
+		// a strip beyond the right border (last group): no pixels, but the wave stores its share of the rows
+		int r_lo, r_hi, len;
+		segment_rows(G, id.seg, Tr, r_lo, r_hi, len);
+		const int n_slots = (r_hi - r_lo + 6 + 5) / 6 * 6;  // as forward_stream_body walks them
+		for (int k = 0; k < n_slots; k++)
+		{
+			const int r = r_lo - 6 + k;  // slot v = r_lo - 3 + k stores row v - 3
+			__syncthreads();
+			group_drain(gc, (uint32_t)lane * 16u, k & 1, r, (r >= r_lo) && (r < r_hi), Tc);
+		}
+		return;
+	}
+	const bool vedge = segment_needs_border_code(G, id.seg, Tr);
+	const bool cfast = (P.color == C_YCOCG || P.color == C_YCOCG_Q) && P.discard == 0;
+#define AKO_FWD_GRP(H, V)                                                                                          \
+	do                                                                                                             \
+	{                                                                                                              \
+		if (cfast)                                                                                                 \
+			forward_stream_body<KIND, 2, true, false, H, V, 0, true, 2, U8_RING, false, CH, true>(P, G, id, lc, lane, &gc);  \
+		else                                                                                                       \
+			forward_stream_body<KIND, 2, true, false, H, V, 0, false, 2, U8_RING, false, CH, true>(P, G, id, lc, lane, &gc); \
+	} while (0)
+	// (REPEAT has no border lanes to patch, but its wrapped lanes fetch from the other end of the row: not the
+	// 16 * lane + constant the interior bodies address their pixels with)
+	const bool hedge = lc.hedge || (c_base < 0) || (c_base + 128 > Tc);
+	if (__builtin_expect(vedge, 0))
+	{
+		if (hedge)
+			AKO_FWD_GRP(true, true);
+		else
+			AKO_FWD_GRP(false, true);
+	}
+	else
+	{
+		if (hedge)
+			AKO_FWD_GRP(true, false);
+		else
+			AKO_FWD_GRP(false, false);
+	}
+#undef AKO_FWD_GRP
+}
+
 // ---------------------------------------------------------------------------------------------
 // Inverse.  NPL = planes handled by one wave: 2 with U8 (the workgroup is then exactly one PAIR of
 // waves working on the same strip and segment, see the file header), 1 on int16 planes.
@@ -1550,6 +1875,15 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				raw.ll[p] = raw.c[p] = raw.b[p] = raw.d[p] = (uint32_t)v;
 			return;
 		}
+#ifdef AKO_MEASURE
+		if (P.dbg & 32768)  // bit 15: the real arithmetic on constant coefficients (no loads)
+		{
+#pragma unroll
+			for (int p = 0; p < NPL; p++)
+				raw.ll[p] = raw.c[p] = raw.b[p] = raw.d[p] = 0x00010002u;
+			return;
+		}
+#endif
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
 		{
@@ -1686,7 +2020,11 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				}
 				__syncthreads();
 				const int y = 2 * r + pair;
+#ifdef AKO_MEASURE
+				const bool row_ok = (r >= r_lo) && (r < r_hi) && (y < oh) && !(P.dbg & 65536);  // bit 16: no pixel stores
+#else
 				const bool row_ok = (r >= r_lo) && (r < r_hi) && (y < oh);  // wave-uniform; phantom last row dropped (lifting.c:112,141)
+#endif
 				if (row_ok)
 				{
 					const uint4 g0 = xbuf[K & 1][pair][0][lane], g1 = xbuf[K & 1][pair][1][lane];
@@ -1722,6 +2060,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						__builtin_amdgcn_raw_buffer_store_b96(u32x3{px[0], px[1], px[2]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
 					else
 						__builtin_amdgcn_raw_buffer_store_b128(u32x4{px[0], px[1], px[2], px[3]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
+					AKO_STORE_GUARD();  // (see store_b128_guarded)
 				}
 			}
 			else if constexpr (U8)

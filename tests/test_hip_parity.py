@@ -355,6 +355,59 @@ def test_fused2_levels_0_and_1_in_one_workgroup_walk(po):
                     assert np.array_equal(back[k], od), (tag, k)
 
 
+def test_column_groups_at_level_0(po):
+    """AKO_HIP_GROUP=1 (off by default): level 0 of big RGBA tiles in column groups (k_forward_group_u8): workgroups of four strips whose stores go
+    through LDS row buffers and leave as whole cache lines, each group owning 448 columns per plane from a start that
+    depends on where the tile's stream lies in memory (the planes' one-value heads shift it by a column each), and the
+    low-pass planes in scratch shifted by the same phase for level 1 to read.  AKO_HIP_GROUP_MIN lowers the size it
+    starts at so that one group, two groups, the first / last group's border lines, strips beyond the right border,
+    tiles and batches whose streams start at other phases, odd heights, every border rule and both colour paths are
+    covered at test sizes -- streams byte-for-byte against the oracle, decoded pixels bit-exact."""
+    nrng = np.random.default_rng(777)
+    cases = [(128, 64, 0), (256, 97, 0), (896, 50, 0), (1024, 96, 0), (1152, 201, 0), (2048, 136, 0), (2816, 120, 0), (4096, 77, 0),
+             (8192, 40, 0), (1024, 768, 256), (1536, 512, 512), (2048, 1100, 512), (5760, 64, 0), (640, 300, 128)]
+    knobs = [{}, {"AKO_HIP_SEG_ROWS": 6}, {"AKO_HIP_SEG_ROWS": 7}, {"AKO_HIP_SEG_ROWS": 40}]
+    n_grouped = 0
+    for path in ("auto", "stream"):
+        for ci, (w, h, tiles) in enumerate(cases):
+            for wavelet in (0, 1):
+                env = dict(knobs[(ci + wavelet) % len(knobs)], AKO_HIP_PATH=path, AKO_HIP_GROUP=1, AKO_HIP_GROUP_MIN=64)
+                wrap = int(nrng.integers(0, 4))
+                q = int(nrng.choice([0, 1, 7, 16, 40]))
+                g = int(nrng.choice([0, 0, 5, 16]))
+                color = int(nrng.choice([0, 0, 0, 1, 2, 3]))
+                discard = int(nrng.random() < 0.2)
+                batch = 3 if (w * h <= 1024 * 200 and ci % 2 == 0) else 1
+                imgs = [(po.gen_image(0, w, h, int(nrng.integers(1, 1 << 30))) if nrng.random() < 0.5
+                         else nrng.integers(0, 256, (h, w, 4), dtype=np.uint8)) for _ in range(batch)]
+                s = po.settings(wavelet=wavelet, wrap=wrap, color=color, compression=2, q=q, g=g, tiles=tiles, discard=discard)
+                blobs = []
+                for img in imgs:
+                    ob, st = po.encode_image(s, img)
+                    assert st == 0
+                    blobs.append(ob)
+                s.color = po.effective_color(s)
+                with _with_env(env):
+                    with api.Plan(_to_api(s), 4, w, h, batch=batch) as plan:
+                        plan.set_profiling(True)
+                        d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).cuda())
+                        d_back = plan.decode(d_streams)
+                        plan.synchronize()
+                        enc_names = [r["name"] for r in plan.kernel_records(False)]
+                        bodies = d_streams.cpu().numpy().reshape(batch, -1).view(np.uint8)
+                        back = d_back.cpu().numpy().reshape(batch, h, w, 4)
+                tag = (path, w, h, tiles, wavelet, wrap, color, discard, q, g, env)
+                grouped = any(n.startswith("fwd_group_") for n in enc_names)
+                n_grouped += grouped
+                if path == "stream" and (tiles or w) >= 512 and h >= 64:
+                    assert grouped, (tag, enc_names[:3])
+                for k in range(batch):
+                    assert np.array_equal(bodies[k], blobs[k][16:]), (tag, k, grouped)
+                    od, _, _ = po.decode_image(blobs[k])
+                    assert np.array_equal(back[k], od), (tag, k)
+    assert n_grouped >= 30, n_grouped
+
+
 def test_shipped_library_ignores_the_measurement_switch(po):
     """AKO_HIP_DBG selects measurement kernels (loads / stores without arithmetic: garbage output) in -DAKO_MEASURE
     builds only.  The shipped library neither holds those kernels nor reads the variable: with every bit set it must still
