@@ -58,6 +58,9 @@ __device__ __forceinline__ void static_for(F&& f)
 // of a pair relies on finding the first one's lines in L2); on the inverse side non-temporal stream loads and
 // pixel stores take 4-5 % off the level-0 kernel run alone but cost 5 % of the throughput with four steps in
 // flight.  (-DAKO_INV_POLICY=2 rebuilds with the inverse hint for experiments.)
+#ifndef AKO_CUT
+#define AKO_CUT 0  // measurement builds: parts of the level-0 forward arithmetic compiled out (see forward_stream_body)
+#endif
 #ifndef AKO_INV_POLICY
 #define AKO_INV_POLICY 0
 #endif
@@ -252,7 +255,7 @@ __device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdg
 		fix_halo_lanes(E0, E1, ed);
 
 	V eR0 = from_next_lane(E0);
-	V eL = 0, eR1 = 0;
+	V eL = (V)0, eR1 = (V)0;
 	if (KIND == K_DD137)
 		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
@@ -273,7 +276,7 @@ __device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdg
 		fix_halo_lanes(H0, H1, ed);
 
 	V hL1 = from_prev_lane(H1);
-	V hL0 = 0, hR0 = 0;
+	V hL0 = (V)0, hR0 = (V)0;
 	if (KIND == K_DD137)
 		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
@@ -306,7 +309,7 @@ __device__ __forceinline__ void hlift_inverse(V L0, V L1, V H0, V H1, const HEdg
 		fix_halo_lanes(H0, H1, ed);
 
 	V hL1 = from_prev_lane(H1);
-	V hL0 = 0, hR0 = 0;
+	V hL0 = (V)0, hR0 = (V)0;
 	if (KIND == K_DD137)
 		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
@@ -327,7 +330,7 @@ __device__ __forceinline__ void hlift_inverse(V L0, V L1, V H0, V H1, const HEdg
 		fix_halo_lanes(E0, E1, ed);
 
 	V eR0 = from_next_lane(E0);
-	V eL = 0, eR1 = 0;
+	V eL = (V)0, eR1 = (V)0;
 	if (KIND == K_DD137)
 		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
@@ -377,7 +380,7 @@ __device__ __forceinline__ void vstep_forward(VFwd<V>& s, V E, V O, int v, int w
 		if (u >= T)
 			H = (wrap == W_ZERO) ? (V)0 : hC;  // HP[T] := HP[T-1]
 		if (u < 0 && wrap == W_ZERO)
-			H = 0;
+			H = (V)0;
 		if (u == 0 && wrap != W_ZERO)
 			hB = H, hC = H;  // HP[-2] = HP[-1] := HP[0]
 	}
@@ -418,7 +421,7 @@ __device__ __forceinline__ void vstep_inverse(VInv<V>& s, V LP, V HP, int v, int
 		if (re >= T)
 			Ev = (wrap == W_ZERO) ? (V)0 : eC;  // E[T] := E[T-1]
 		if (re < 0 && wrap == W_ZERO)
-			Ev = 0;
+			Ev = (V)0;
 		if (ro == 0)
 			eA = (wrap == W_ZERO) ? (V)0 : eB;  // E[-1] := E[0]
 	}
@@ -1350,6 +1353,15 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 						px[1] = __builtin_amdgcn_alignbit(raw.a[par].y, raw.a[par].x, 24);
 					}
 					V v0[4], v1[4];
+#ifdef AKO_MEASURE
+					if (AKO_CUT & 8 || (P.dbg & 524288))  // bit 19 / AKO_CUT 8: no pixel decoding (the raw bits taken as samples)
+					{
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							v0[k] = (V)__uint_as_float(px[k]), v1[k] = (V)__uint_as_float(px[k] ^ 0x00400000u);
+					}
+					else
+#endif
 					if constexpr (CFAST)
 						decode_pixels_ycocg<V>(px, (P.color == C_YCOCG_Q) ? (V)2 : (V)1, (int)id.pg, v0, v1);
 					else
@@ -1390,11 +1402,31 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				if (one_plane && p == 1)  // wave-uniform
 					continue;
 				V e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
-				hlift_forward<KIND, NARROW, HEDGE, V>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], lc.he,
-				                                      e[0], e[1], e[2], e[3]);
-				hlift_forward<KIND, NARROW, HEDGE, V>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], lc.he,
-				                                      o[0], o[1], o[2], o[3]);
+#ifdef AKO_MEASURE
+				if (AKO_CUT & 2 || (P.dbg & 262144))  // bit 18 / AKO_CUT 2: no row pass
+				{
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						e[k] = smp[0][p][k], o[k] = smp[1][p][k];
+				}
+				else
+#endif
+				{
+					hlift_forward<KIND, NARROW, HEDGE, V>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], lc.he,
+					                                      e[0], e[1], e[2], e[3]);
+					hlift_forward<KIND, NARROW, HEDGE, V>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], lc.he,
+					                                      o[0], o[1], o[2], o[3]);
+				}
 				V lp[4], hp[4];
+#ifdef AKO_MEASURE
+				if (AKO_CUT & 4 || (P.dbg & 1048576))  // bit 20 / AKO_CUT 4: no column pass
+				{
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						lp[k] = e[k], hp[k] = o[k];
+				}
+				else
+#endif
 #pragma unroll
 				for (int k = 0; k < 4; k++)
 					vstep_forward<KIND, NARROW, VEDGE, K, V>(st[p][k], e[k], o[k], v, wrap, Tr, lp[k], hp[k]);
@@ -1402,6 +1434,15 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 				// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP)
 				const float gf = (p_first + p * P_STEP == 0) ? gf_luma : gf_chroma;
 				const float rq = (p_first + p * P_STEP == 0) ? P.rq_luma : P.rq_chroma;
+#ifdef AKO_MEASURE
+				if constexpr (!NARROW)
+				if (AKO_CUT & 1 || (P.dbg & 131072))  // bit 17 / AKO_CUT 1: no gate / quantizer (values packed as they are)
+				{
+					pack2x2_f(lp[0], lp[1], hp[0], hp[1], w_ll[p], w_c[p]);
+					pack2x2_f(lp[2], lp[3], hp[2], hp[3], w_b[p], w_d[p]);
+					continue;
+				}
+#endif
 				pack_row_f(lp, hp, gf, rq, w_ll[p], w_c[p], w_b[p], w_d[p]);
 
 			}
@@ -1579,12 +1620,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5))) vo
 // register), the top / bottom border bodies -- three row segments in a hundred -- spill a few dozen registers to
 // scratch and are the only ones that do.
 #ifndef AKO_U8_RING
-#define AKO_U8_RING 2
+#define AKO_U8_RING 1
 #endif
 #ifndef AKO_U8_WAVES
 #define AKO_U8_WAVES 4
 #endif
-constexpr int U8_RING = AKO_U8_RING;  // row slots the u8 forward kernel fetches ahead (2, 3 or 6)
+constexpr int U8_RING = AKO_U8_RING;  // row slots the u8 forward kernel fetches ahead (1, 2, 3 or 6; round 3: 1 -- the kernel is bound by
+                                      // instruction issue, a second slot in flight buys nothing and costs eight registers: -3 % alone)
 
 // Measurement builds only (-DAKO_MEASURE, scripts/build_variant.sh): the shipped library neither holds these kernels nor
 // reads AKO_HIP_DBG.
@@ -2205,6 +2247,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 // waves -- neighbouring strips, which the barriers of the per-slot LDS exchange then keep on the same rows
 // (StreamGeom::lockstep); 8 KB of dynamic LDS per pair.
 // OPT = optimistic fp32 pipeline; the exact re-run behind it (OPT = false) returns at once unless flagged.
+#ifndef AKO_U8_INV_PF
+#define AKO_U8_INV_PF 1
+#endif
+constexpr int U8_INV_PF = AKO_U8_INV_PF;  // row slots the u8 inverse kernel fetches ahead (1 or 2; round 3: 1, -3 % alone, as U8_RING)
 constexpr uint32_t INV_U8_LDS_PER_PAIR = 2 * 2 * 2 * 64 * sizeof(uint4);
 template <int KIND, bool OPT, int CH = 4>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVES, AKO_U8_WAVES))) void k_inverse_stream_u8(const LevelParams P, const StreamGeom G)
@@ -2225,16 +2271,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	if (__builtin_expect(vedge, 0))
 	{
 		if (lc.hedge)
-			inverse_stream_body<KIND, 2, true, OPT, true, true, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, true, true, 0, U8_INV_PF, false, CH>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, 2, true, OPT, false, true, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, false, true, 0, U8_INV_PF, false, CH>(P, G, id, lc, lane, xbuf);
 	}
 	else
 	{
 		if (lc.hedge)
-			inverse_stream_body<KIND, 2, true, OPT, true, false, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, true, false, 0, U8_INV_PF, false, CH>(P, G, id, lc, lane, xbuf);
 		else
-			inverse_stream_body<KIND, 2, true, OPT, false, false, 0, 2, false, CH>(P, G, id, lc, lane, xbuf);
+			inverse_stream_body<KIND, 2, true, OPT, false, false, 0, U8_INV_PF, false, CH>(P, G, id, lc, lane, xbuf);
 	}
 }
 
