@@ -526,6 +526,10 @@ def main():
                          "events around every launch (the timed regions themselves carry no events: they cost about 8 % "
                          "of the overlapped throughput); measured_copy_GBps = read + write rate of a 1 GiB device copy, the "
                          "faster of the two copy kernels"),
+                "binding_resource": ("instruction issue (VALU), not HBM, for the u8 level-0 kernels: with every load and store "
+                                     "taken out they run as long as with them, and the SIMDs' VALU pipes are busy > 100 % of the "
+                                     "time (DESIGN.md 5.0, profiles/r3_level0_without_memory.txt, profiles/r3_sq_counters.txt); "
+                                     "'frac' is what that leaves of the memory system"),
                 "timed_region": {"steps_in_flight": nfl, "avg_launch_ms": round(timed_ms, 4),
                                  "achieved": round(dom["bytes"] / (timed_ms * 1e-3) / 1e9, 1),
                                  "frac": round(dom["bytes"] / (timed_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},

@@ -5,6 +5,5 @@ for kv in "$@"; do
   env $kv ${LIB:+AKO_LIB_OVERRIDE=ako_amd/libako_$LIB.so} python bench.py --no-cpu-baseline ${BENCH_ARGS} | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
-ks={(k['name'],k['level']):k['isolated_ms'] for k in d['kernels']}
-print('$kv', 'value', d['value'], 'inflight1', d['value_inflight1'], 'L0 fwd/inv isolated', [v for k,v in ks.items() if k[1]==0][:2])"
+print('$kv', 'value', d['value'], 'inflight1', d['value_inflight1'], 'level 0/1 isolated ms', [(k['name'], k['isolated_ms']) for k in d['kernels'] if k['level'] in (0, 1)][:5])"
 done; done
