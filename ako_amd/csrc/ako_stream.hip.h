@@ -58,6 +58,9 @@ __device__ __forceinline__ void static_for(F&& f)
 // of a pair relies on finding the first one's lines in L2); on the inverse side non-temporal stream loads and
 // pixel stores take 4-5 % off the level-0 kernel run alone but cost 5 % of the throughput with four steps in
 // flight.  (-DAKO_INV_POLICY=2 rebuilds with the inverse hint for experiments.)
+#ifndef AKO_PERM
+#define AKO_PERM 0  // 1: the row pass takes its neighbours' values through ds_bpermute (LDS pipe) instead of DPP moves (VALU)
+#endif
 #ifndef AKO_CUT
 #define AKO_CUT 0  // measurement builds: parts of the level-0 forward arithmetic compiled out (see forward_stream_body)
 #endif
@@ -90,6 +93,15 @@ __device__ __forceinline__ float from_prev_lane(float x)
 __device__ __forceinline__ float from_next_lane(float x)
 {
 	return __int_as_float(from_next_lane(__float_as_int(x)));
+}
+// the same shifts on the LDS pipe (ds_bpermute_b32: no LDS memory involved, no VALU cycles): idx = 4 * source lane
+__device__ __forceinline__ int perm_lane(int idx, int x)
+{
+	return __builtin_amdgcn_ds_bpermute(idx, x);
+}
+__device__ __forceinline__ float perm_lane(int idx, float x)
+{
+	return __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(x)));
 }
 __device__ __forceinline__ int read_lane(int x, int lane)
 {
@@ -193,6 +205,7 @@ struct HEdge
 	                         // that side to hold the border values (see edge_taps)
 	int lane_first, lane_last;
 	int wrap;
+	int perm_prev, perm_next;  // AKO_PERM: 4 * (lane - 1), 4 * (lane + 1) (mod 64): ds_bpermute addresses of the neighbours
 };
 
 // overwrite the out-of-range lanes of a two-column sequence (a0 = column c0, a1 = column c1) with
@@ -251,13 +264,15 @@ __device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdg
 		H0 = nrw<true>(O0 - E0), H1 = nrw<true>(O1 - E1);
 		return;
 	}
+	auto LP = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_prev, x); else return from_prev_lane(x); };
+	auto LN = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_next, x); else return from_next_lane(x); };
 	if (HEDGE)
 		fix_halo_lanes(E0, E1, ed);
 
-	V eR0 = from_next_lane(E0);
+	V eR0 = LN(E0);
 	V eL = (V)0, eR1 = (V)0;
 	if (KIND == K_DD137)
-		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+		eL = LP(E1), eR1 = LN(E1);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
 	{
 		const BorderVals<V> b = border_values(E0, E1, ed);
@@ -275,10 +290,10 @@ __device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdg
 	if (HEDGE)
 		fix_halo_lanes(H0, H1, ed);
 
-	V hL1 = from_prev_lane(H1);
+	V hL1 = LP(H1);
 	V hL0 = (V)0, hR0 = (V)0;
 	if (KIND == K_DD137)
-		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+		hL0 = LP(H0), hR0 = LN(H0);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
 	{
 		const BorderVals<V> b = border_values(H0, H1, ed);
@@ -305,13 +320,15 @@ __device__ __forceinline__ void hlift_inverse(V L0, V L1, V H0, V H1, const HEdg
 		O0 = lift_add<NRW>(L0, H0, 0), O1 = lift_add<NRW>(L1, H1, 0);
 		return;
 	}
+	auto LP = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_prev, x); else return from_prev_lane(x); };
+	auto LN = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_next, x); else return from_next_lane(x); };
 	if (HEDGE)
 		fix_halo_lanes(H0, H1, ed);
 
-	V hL1 = from_prev_lane(H1);
+	V hL1 = LP(H1);
 	V hL0 = (V)0, hR0 = (V)0;
 	if (KIND == K_DD137)
-		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+		hL0 = LP(H0), hR0 = LN(H0);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
 	{
 		const BorderVals<V> b = border_values(H0, H1, ed);
@@ -329,10 +346,10 @@ __device__ __forceinline__ void hlift_inverse(V L0, V L1, V H0, V H1, const HEdg
 	if (HEDGE)
 		fix_halo_lanes(E0, E1, ed);
 
-	V eR0 = from_next_lane(E0);
+	V eR0 = LN(E0);
 	V eL = (V)0, eR1 = (V)0;
 	if (KIND == K_DD137)
-		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+		eL = LP(E1), eR1 = LN(E1);
 	if (HEDGE && (ed.nh_left || ed.nh_right))
 	{
 		const BorderVals<V> b = border_values(E0, E1, ed);
@@ -614,6 +631,7 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	lc.c0 = c_base + 2 * lane;
 	lc.net = wide || ((lane >= 2) && (lane < 62));
 	lc.he.wrap = wrap;
+	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
 	lc.he.left = (wrap != W_REPEAT) && (c_base < 0);
 	lc.he.right = (wrap != W_REPEAT) && (c_base + 128 > Tc);
 	lc.he.nh_left = wide;
@@ -652,6 +670,7 @@ __device__ __forceinline__ LaneCols lane_columns_at(int c_base, int net_lo, int 
 	lc.c0 = c_base + 2 * lane;
 	lc.net = (lane >= net_lo) && (lane < net_hi);
 	lc.he.wrap = wrap;
+	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
 	lc.he.left = (wrap != W_REPEAT) && (c_base < 0);
 	lc.he.right = (wrap != W_REPEAT) && (c_base + 128 > Tc);
 	lc.he.nh_left = lc.he.nh_right = false;

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <time.h>
 
 struct lane
 {
@@ -34,6 +35,8 @@ struct lane
 	uint8_t* pin_out;                /* image_bytes: pixels on their way back (decode) */
 	pthread_t thread;
 	int started;
+	double busy_s; /* the last call: time this lane spent on its images, and how many it took */
+	size_t images;
 };
 
 struct akoHipBatch
@@ -253,13 +256,20 @@ static void* lane_main(void* arg)
 		const size_t i = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
 		if (i >= b->n)
 			return NULL;
+		struct timespec t0, t1;
+		clock_gettime(CLOCK_MONOTONIC, &t0);
 		set_status(b, i, b->decode ? decode_one(L, i) : encode_one(L, i));
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		L->busy_s += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+		L->images++;
 	}
 }
 
 static int run_call(struct akoHipBatch* b)
 {
 	b->next = 0, b->failed = 0;
+	for (size_t k = 0; k < b->n_lanes; k++)
+		b->lanes[k].busy_s = 0.0, b->lanes[k].images = 0;
 	size_t lanes = b->n_lanes < b->n ? b->n_lanes : b->n;
 	for (size_t k = 0; k < lanes; k++)
 		b->lanes[k].started = (pthread_create(&b->lanes[k].thread, NULL, lane_main, &b->lanes[k]) == 0);
@@ -396,4 +406,18 @@ AKO_API int akoHipDecodeBatch(akoHipBatch* b, size_t n_blobs, const void* const*
 	const int rc = run_call(b);
 	__atomic_store_n(&b->busy, 0, __ATOMIC_RELEASE);
 	return rc;
+}
+
+/* what lane `lane` did in the last call: its device, the time it spent on its images, how many it took (1: lane exists) */
+AKO_API int akoHipBatchLaneStats(const akoHipBatch* b, size_t lane, int* device, double* busy_seconds, size_t* images)
+{
+	if (b == NULL || lane >= b->n_lanes)
+		return 0;
+	if (device)
+		*device = b->lanes[lane].device;
+	if (busy_seconds)
+		*busy_seconds = b->lanes[lane].busy_s;
+	if (images)
+		*images = b->lanes[lane].images;
+	return 1;
 }

@@ -549,8 +549,19 @@ struct band
 	enum akoStatus status;
 	pthread_t thread;
 	int started;
+	double seconds; /* plan creation + transform + entropy stage + copies of this band */
 };
 
+/* the bands of this thread's last akoEncodeExt / akoDecodeExt that was split over devices (akoHipLastBands) */
+static __thread struct
+{
+	size_t n;
+	int device[MAX_BANDS];
+	double seconds[MAX_BANDS];
+	size_t rows[MAX_BANDS];
+} g_last_bands;
+
+static void* band_main_timed(void* arg);
 static void* band_main(void* arg)
 {
 	struct band* b = arg;
@@ -565,19 +576,33 @@ static void* band_main(void* arg)
 	return NULL;
 }
 
+static void* band_main_timed(void* arg)
+{
+	struct band* b = arg;
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	band_main(arg);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	b->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+	return NULL;
+}
+
 /* bands[0 .. n) filled in by the caller; runs them (band 0 on the calling thread) and returns the first failure */
 static enum akoStatus run_bands(struct band* bands, size_t n)
 {
 	for (size_t k = 1; k < n; k++)
-		bands[k].started = (pthread_create(&bands[k].thread, NULL, band_main, &bands[k]) == 0);
-	band_main(&bands[0]);
+		bands[k].started = (pthread_create(&bands[k].thread, NULL, band_main_timed, &bands[k]) == 0);
+	band_main_timed(&bands[0]);
 	for (size_t k = 1; k < n; k++)
 	{
 		if (bands[k].started)
 			pthread_join(bands[k].thread, NULL);
 		else
-			band_main(&bands[k]);
+			band_main_timed(&bands[k]);
 	}
+	g_last_bands.n = n < MAX_BANDS ? n : MAX_BANDS;
+	for (size_t k = 0; k < g_last_bands.n; k++)
+		g_last_bands.device[k] = bands[k].device, g_last_bands.seconds[k] = bands[k].seconds, g_last_bands.rows[k] = bands[k].rows;
 	enum akoStatus st = AKO_OK;
 	for (size_t k = 0; k < n; k++)
 	{
@@ -660,6 +685,7 @@ AKO_API size_t akoEncodeExt(const struct akoCallbacks* c, const struct akoSettin
 		int devs[MAX_BANDS];
 		const size_t nd = device_list(devs, MAX_BANDS);
 		const size_t td = st.tiles_dimension;
+		g_last_bands.n = 0;
 		if (nd > 1 && td != 0 && image_h > td)
 		{
 			struct band bands[MAX_BANDS];
@@ -980,6 +1006,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 		int devs[MAX_BANDS];
 		const size_t nd = device_list(devs, MAX_BANDS);
 		const size_t td = st.tiles_dimension;
+		g_last_bands.n = 0;
 		if (nd > 1 && td != 0 && image_h > td)
 		{
 			struct band bands[MAX_BANDS];
@@ -1547,4 +1574,21 @@ failure:
 	if (out_status != NULL)
 		*out_status = status;
 	return 0;
+}
+
+/* The bands of the calling thread's last akoEncodeExt / akoDecodeExt that was split over devices (AKO_HIP_DEVICES): device,
+ * seconds (plan, transform, entropy stage, copies) and image rows of each, in band order; returns their number. */
+AKO_API size_t akoHipLastBands(int* devices, double* seconds, size_t* rows, size_t cap)
+{
+	const size_t n = g_last_bands.n < cap ? g_last_bands.n : cap;
+	for (size_t k = 0; k < n; k++)
+	{
+		if (devices)
+			devices[k] = g_last_bands.device[k];
+		if (seconds)
+			seconds[k] = g_last_bands.seconds[k];
+		if (rows)
+			rows[k] = g_last_bands.rows[k];
+	}
+	return g_last_bands.n;
 }

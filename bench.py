@@ -69,6 +69,13 @@ def parse(argv=None):
                     help="steps in flight: consecutive steps alternate over this many HIP streams / buffer sets")
     ap.add_argument("--min-region", type=float, default=0.25,
                     help="shortest timed region in seconds: a region is as many passes of the K steps as it takes (0: exactly K steps)")
+    ap.add_argument("--route", default="ranks", choices=["ranks", "lanes", "bands"],
+                    help="ranks (default): one process per GPU, device resident; lanes: ONE process, akoHipBatch lanes over the "
+                         "devices of --route-devices, host images in / blobs out / images back (workload batch4k); bands: ONE "
+                         "process, akoEncodeExt / akoDecodeExt of one tiled image cut into bands of tile rows over the devices "
+                         "(AKO_HIP_DEVICES; workload tiles16k).  Both host-memory routes include the link and the entropy stage")
+    ap.add_argument("--route-devices", default="all", help="device list of the lanes / bands routes, e.g. 0,1,2,3 or 0,0 (a "
+                                                            "rehearsal on one GPU); all = every visible device")
     ap.add_argument("--repeats", type=int, default=11,
                     help="timed regions of K steps each; `value` is their median (SURVEY 8d: median of >= 10)")
     return ap.parse_args(argv)
@@ -289,8 +296,138 @@ def rehearsal_without_gpu(args, rank, world):
         dist.destroy_process_group()
 
 
+def host_route(args) -> int:
+    """The in-process multi-device routes: no torch.distributed, one process drives every device.  Prints one
+    JSON line: whole-job Mpx/s of encode + decode THROUGH HOST MEMORY (link and entropy stage included -- not comparable
+    with the device-resident default line), per-device busy time and the slowest device."""
+    import ctypes as C
+    import time
+
+    import numpy as np
+    import torch
+
+    from ako_amd import api
+
+    n_vis = torch.cuda.device_count()
+    devices = list(range(n_vis)) if args.route_devices == "all" else [int(x) for x in args.route_devices.split(",") if x != ""]
+    assert devices and all(0 <= d < max(n_vis, 1) for d in devices), f"--route-devices {args.route_devices}: {n_vis} visible"
+    L = api.lib()
+    per_dev = {}
+    if args.route == "lanes":
+        assert args.workload == "batch4k", "--route lanes: --workload batch4k (configs[3]: 64 images of 3840x2160)"
+        w, h, ch, n_img = 3840, 2160, 4, 64
+        s = api.settings(wavelet=api.DD137, wrap=api.CLAMP, compression=api.KAGARI, q=16, g=16, color=api.YCOCG)
+        base = [api.synth_image(0, w, h, seed=0x9E3779B9 + j) for j in range(8)]
+        imgs = []
+        for j in range(n_img):  # pinned inputs: the lanes copy from them at link rate
+            a = api.pinned_empty((h, w, ch))
+            a[...] = base[j % 8]
+            imgs.append(a)
+        outs = [api.pinned_empty((h, w, ch)) for _ in range(n_img)]
+        L.akoHipBatchLaneStats.restype = C.c_int
+        L.akoHipBatchLaneStats.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_size_t)]
+        with api.Batch(s, ch, w, h, devices=devices) as b:
+            def stats(tag):
+                for k in range(b.lanes):
+                    d, t, n = C.c_int(), C.c_double(), C.c_size_t()
+                    L.akoHipBatchLaneStats(b._b, k, C.byref(d), C.byref(t), C.byref(n))
+                    e = per_dev.setdefault(d.value, {"lanes": 0, "encode_busy_s": 0.0, "decode_busy_s": 0.0, "images": 0})
+                    e[tag + "_busy_s"] += t.value
+                    if tag == "encode":
+                        e["lanes"] += 1
+                        e["images"] += n.value
+            blobs, st = b.encode(imgs)  # warm-up (plans, pinned staging) + the blobs the decode passes use
+            assert not any(st), st
+            back, st = b.decode(blobs, outs)
+            assert not any(st) and all(np.array_equal(back[j], back[j % 8]) for j in range(8, n_img, 8))
+            enc_s = dec_s = 0.0
+            for _ in range(max(1, args.steps)):
+                t0 = time.perf_counter()
+                blobs, st = b.encode(imgs)
+                t1 = time.perf_counter()
+                stats("encode")
+                back, st2 = b.decode(blobs, outs)
+                t2 = time.perf_counter()
+                stats("decode")
+                assert not any(st) and not any(st2)
+                enc_s += t1 - t0
+                dec_s += t2 - t1
+            lanes = b.lanes
+        steps = max(1, args.steps)
+        px = float(n_img * w * h) * steps
+        workload = "configs[3]: 64 x 3840x2160 RGBA images, host pixels -> .ako blobs (Kagari) -> host pixels, akoHipBatch lanes"
+        extra = {"lanes": lanes, "encode_Mpx_s": round(px / enc_s / 1e6, 1), "decode_Mpx_s": round(px / dec_s / 1e6, 1),
+                 "blob_bytes_per_image": int(np.mean([x.size for x in blobs]))}
+        elapsed = enc_s + dec_s
+        for e in per_dev.values():  # per step
+            e["lanes"] //= steps
+            e["images"] //= steps
+            e["encode_busy_s"], e["decode_busy_s"] = round(e["encode_busy_s"] / steps, 4), round(e["decode_busy_s"] / steps, 4)
+            e["busy_s_per_lane"] = round((e["encode_busy_s"] + e["decode_busy_s"]) / max(e["lanes"], 1), 4)
+        slow = max(per_dev, key=lambda d: per_dev[d]["busy_s_per_lane"])
+    else:
+        assert args.workload == "tiles16k", "--route bands: --workload tiles16k (configs[4]: one tiled 16384x16384 image)"
+        td = int(os.environ.get("AKO_BENCH_TILES", "512"))
+        w = h = 16384
+        os.environ["AKO_HIP_DEVICES"] = ",".join(str(d) for d in devices)
+        s = api.settings(wavelet=api.CDF53, wrap=api.CLAMP, compression=api.KAGARI, q=0, g=0, tiles=td)
+        img = api.synth_image(0, w, h, seed=0x9E3779B9)
+        L.akoHipLastBands.restype = C.c_size_t
+        L.akoHipLastBands.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_size_t), C.c_size_t]
+
+        def bands(tag):
+            dv, sec, rows = (C.c_int * 16)(), (C.c_double * 16)(), (C.c_size_t * 16)()
+            n = L.akoHipLastBands(dv, sec, rows, 16)
+            for k in range(n):
+                e = per_dev.setdefault(dv[k], {"bands": 0, "rows": 0, "encode_busy_s": 0.0, "decode_busy_s": 0.0})
+                e[tag + "_busy_s"] += sec[k]
+                if tag == "encode":
+                    e["bands"] += 1
+                    e["rows"] += rows[k]
+            return n
+        blob = api.encode(img, s)  # warm-up
+        back = api.decode(blob)[0]
+        assert np.array_equal(back, img), "round trip of the lossless tiled image"
+        del back
+        enc_s = dec_s = 0.0
+        steps = max(1, args.steps)
+        n_bands = 0
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            blob = api.encode(img, s)
+            t1 = time.perf_counter()
+            n_bands = bands("encode")
+            back = api.decode(blob)[0]
+            t2 = time.perf_counter()
+            bands("decode")
+            del back
+            enc_s += t1 - t0
+            dec_s += t2 - t1
+        px = float(w * h) * steps
+        workload = f"configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles {td}, host pixels -> .ako (Kagari) -> host pixels, bands of tile rows over the devices"
+        extra = {"bands": n_bands, "encode_Mpx_s": round(px / enc_s / 1e6, 1), "decode_Mpx_s": round(px / dec_s / 1e6, 1), "blob_bytes": int(blob.size)}
+        elapsed = enc_s + dec_s
+        for e in per_dev.values():  # per step
+            e["bands"] //= steps
+            e["rows"] //= steps
+            e["encode_busy_s"], e["decode_busy_s"] = round(e["encode_busy_s"] / steps, 4), round(e["decode_busy_s"] / steps, 4)
+            e["busy_s_per_band"] = round((e["encode_busy_s"] + e["decode_busy_s"]) / max(e["bands"], 1), 4)
+        slow = max(per_dev, key=lambda d: per_dev[d]["busy_s_per_band"]) if per_dev else devices[0]  # (one device: not split)
+    line = {"metric": "Mpixels/s encode+decode", "value": round(px / elapsed / 1e6, 2), "unit": "Mpx/s",
+            "n_gpus": len(set(devices)), "steps": steps, "warmup": 1, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak" if args.route == "lanes" else "strong", "vs_baseline": None,
+            "dtype": "int32 arithmetic, int16 storage", "data": "synthetic, HOST resident: the link and the entropy stage are inside the timed calls",
+            "config": {"workload": workload, "route": args.route, "devices": devices},
+            "per_device": {str(d): per_dev[d] for d in sorted(per_dev)}, "slowest_device": int(slow), **extra,
+            "note": "in-process multi-device route (DESIGN.md 6); not the device-resident default line, whose `value` is never PCIe-inclusive"}
+    print(json.dumps(line))
+    return 0
+
+
 def main():
     args = parse()
+    if args.route != "ranks":
+        sys.exit(host_route(args))
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args))  # parent: nothing below runs here, and nothing above touched the GPU

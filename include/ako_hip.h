@@ -212,6 +212,8 @@ akoHipBatch* akoHipBatchCreate(const int* devices, size_t n_devices, size_t lane
                                enum akoStatus* out_status);
 void akoHipBatchDestroy(akoHipBatch*);
 size_t akoHipBatchLanes(const akoHipBatch*);
+/* what lane `lane` did in the last call: its device, the time it spent on its images, how many it took; 0: no such lane */
+int akoHipBatchLaneStats(const akoHipBatch*, size_t lane, int* device, double* busy_seconds, size_t* images);
 int akoHipEncodeBatch(akoHipBatch*, size_t n_images, const void* const* images, void** out_blobs, size_t* out_sizes,
                       enum akoStatus* out_status);
 int akoHipDecodeBatch(akoHipBatch*, size_t n_blobs, const void* const* blobs, const size_t* blob_sizes, void** images,
@@ -221,6 +223,10 @@ int akoHipDecodeBatch(akoHipBatch*, size_t n_blobs, const void* const* blobs, co
 void* akoHipHostAlloc(size_t bytes);
 void akoHipHostFree(void* p);
 int akoHipHostIsPinned(const void* p); /* 1: page-locked memory the HIP runtime knows (akoHipHostAlloc, hipHostRegister) */
+
+/* The bands of the calling thread's last akoEncodeExt / akoDecodeExt that was split over devices (AKO_HIP_DEVICES): device,
+ * seconds and image rows of each, in band order (at most `cap` written); returns their number (0: the call was not split). */
+size_t akoHipLastBands(int* devices, double* seconds, size_t* rows, size_t cap);
 
 /* measurement aid: read + write GB/s of a tuned device-to-device copy of `bytes` on the current device (two temporary
  * buffers of that size); the practical memory rate bench.py reports beside the 8 TB/s spec peak.  0 on failure. */

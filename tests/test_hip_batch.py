@@ -203,3 +203,41 @@ def test_ratio_search_on_one_transform_gives_the_blob_of_repeated_encodes(po, go
     assert np.array_equal(b0, api.encode(img512, api.default_settings())) and e0 == 1 and q0 == 16
     b1, q1, _, _ = api.encode_ratio(img512, 1, api.default_settings())
     assert np.array_equal(b1, api.encode(img512, api.settings(q=0, g=0))) and q1 == 0
+
+
+@pytest.mark.gpu
+def test_bench_host_routes_rehearsed_on_one_gpu():
+    """`bench.py --route lanes` (akoHipBatch lanes over devices, configs[3]) and `--route bands` (one tiled image cut over
+    AKO_HIP_DEVICES, configs[4]) print a line with per-device busy time and the slowest device.  Rehearsed on the one GPU of
+    the box with device 0 named twice: the devices then share one memory system and one link, so the two-"device" figure
+    of the lanes route must agree with its one-device figure (not fall below 0.8 of it: the lanes of both halves compete
+    for the same link), and every band / lane must have been used."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(*a, env=None):
+        e = dict(os.environ, **(env or {}))
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *a], capture_output=True, text=True, env=e, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run("--workload", "batch4k", "--route", "lanes", "--route-devices", "0", "--steps", "2")
+    two = run("--workload", "batch4k", "--route", "lanes", "--route-devices", "0,0", "--steps", "2")
+    for line, n_lanes in ((one, 8), (two, 16)):
+        assert line["config"]["route"] == "lanes" and line["lanes"] == n_lanes
+        pd = line["per_device"]["0"]
+        assert pd["images"] == 64 and pd["lanes"] == n_lanes and pd["encode_busy_s"] > 0 and pd["decode_busy_s"] > 0
+        assert line["slowest_device"] == 0
+    assert two["value"] >= 0.8 * one["value"], (one["value"], two["value"])
+
+    env = {"AKO_BENCH_TILES": "512"}
+    one = run("--workload", "tiles16k", "--route", "bands", "--route-devices", "0", "--steps", "1", env=env)
+    two = run("--workload", "tiles16k", "--route", "bands", "--route-devices", "0,0", "--steps", "1", env=env)
+    assert one["bands"] == 0 and two["bands"] == 2  # one device: the call is not split
+    assert two["per_device"]["0"]["rows"] == 16384 and two["per_device"]["0"]["bands"] == 2
+    assert two["per_device"]["0"]["encode_busy_s"] > 0 and two["per_device"]["0"]["decode_busy_s"] > 0
+    # (no rate comparison here: a split call builds a plan per band and parses on fresh threads, which on ONE GPU costs more
+    # than the split saves -- 148 against 459 Mpx/s; DESIGN.md 6)
+    assert two["value"] > 0 and one["value"] > 0
