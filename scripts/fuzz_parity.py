@@ -13,7 +13,8 @@ print("seed", seed, flush=True)
 t_end = time.time() + budget
 done = 0
 knobs = ["AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_LOCKSTEP", "AKO_HIP_FUSE2", "AKO_HIP_INV_PAIRS", "AKO_HIP_FWD_PAIRS",
-         "AKO_HIP_TAIL_MANY", "AKO_HIP_WIDE", "AKO_HIP_STAGED", "AKO_HIP_DEEP", "AKO_KAGARI_THREADS", "AKO_KAGARI_PAR_MIN"]
+         "AKO_HIP_TAIL_MANY", "AKO_HIP_WIDE", "AKO_HIP_STAGED", "AKO_HIP_DEEP", "AKO_KAGARI_THREADS", "AKO_KAGARI_PAR_MIN",
+         "AKO_HIP_GROUP", "AKO_HIP_GROUP_MIN", "AKO_HIP_SEG_ROWS"]
 while time.time() < t_end:
     for k in knobs:
         os.environ.pop(k, None)
@@ -21,6 +22,11 @@ while time.time() < t_end:
         os.environ["AKO_HIP_PATH"] = str(rng.choice(["auto", "stream", "generic"]))
         os.environ["AKO_HIP_LOCKSTEP"] = str(rng.integers(0, 4))
         os.environ["AKO_HIP_FUSE2"] = str(rng.integers(0, 4))
+        os.environ["AKO_HIP_GROUP"] = str(rng.integers(0, 2))
+        os.environ["AKO_HIP_GROUP_MIN"] = str(rng.choice([64, 128, 1024]))
+        os.environ["AKO_HIP_STAGED"] = str(rng.choice([0, 1, 1, 2]))
+        if rng.random() < 0.3:
+            os.environ["AKO_HIP_SEG_ROWS"] = str(rng.choice([2, 6, 7, 12, 40]))
         os.environ["AKO_HIP_INV_PAIRS"] = str(rng.choice([1, 2, 4]))
         os.environ["AKO_HIP_FWD_PAIRS"] = str(rng.choice([1, 2, 4]))
         os.environ["AKO_HIP_TAIL_MANY"] = str(rng.choice([8, 16, 32, 64]))
@@ -29,9 +35,11 @@ while time.time() < t_end:
         os.environ["AKO_KAGARI_THREADS"] = str(rng.choice([1, 4, 16]))
         os.environ["AKO_KAGARI_PAR_MIN"] = str(rng.choice([256, 4096, 131072]))
         if rng.random() < 0.3:
-            os.environ["AKO_HIP_TAIL"] = str(rng.integers(0, 3))
+            os.environ["AKO_HIP_TAIL"] = str(rng.integers(0, 2))
     big = rng.random() < 0.25
     w = int(rng.integers(3, 2600 if big else 400)); h = int(rng.integers(3, 1800 if big else 400))
+    if rng.random() < 0.35:  # the column-group kernel wants multiples of 128, the native RGB kernels multiples of 4
+        w = int(rng.choice([128, 256, 384, 512, 896, 1024, 1152, 2048, 2560])) if rng.random() < 0.6 else (w + 3) // 4 * 4
     ch = int(rng.choice([1, 2, 3, 4, 4, 4, 5]))
     wavelet = int(rng.choice([0, 0, 1, 2, 3])); wrap = int(rng.integers(0, 4)); color = int(rng.integers(0, 4))
     tiles = int(rng.choice([0, 0, 0, 8, 16, 32, 64, 128, 256, 512]))
