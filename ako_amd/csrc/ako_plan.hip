@@ -143,6 +143,7 @@ struct Tuning
 	int fuse2 = 0;         // AKO_HIP_FUSE2: levels 0 and 1 of eligible RGBA plans in one workgroup walk, the level-0 low-pass plane
 	                       // handed over through LDS (ako_fused.hip.h): bit 0 forward, bit 1 inverse.  Bit-exact and parity-tested,
 	                       // off by default: measured slower than the level-per-kernel launches
+	int pack = 1;          // AKO_HIP_PACK: levels of 8..64 columns of tiled images run several tiles per wave (0: one tile per wave)
 	int group = 0;         // AKO_HIP_GROUP: level 0 of big RGBA tiles in column groups, the stores re-shaped into whole cache lines
 	                       // (k_forward_group_u8, ako_stream.hip.h).  Bit-exact and parity-tested, off by default: the level-0
 	                       // kernels turned out to be bound by instruction issue, not by their stores
@@ -186,6 +187,7 @@ struct Tuning
 		if (t.inv_pairs != 1 && t.inv_pairs != 4)
 			t.inv_pairs = 2;
 		t.fuse2 = num("AKO_HIP_FUSE2", 0) & 3;
+		t.pack = num("AKO_HIP_PACK", 1) != 0;
 		t.group = num("AKO_HIP_GROUP", 0);
 		t.group_min = num("AKO_HIP_GROUP_MIN", 1024);
 		t.f2_rows = num("AKO_HIP_F2_ROWS", 0);
@@ -462,12 +464,30 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 	return L.tw >= 64 && L.th >= 12;
 }
 
+uint64_t scratch_plane_elems(const Group& g, int which);
+
+// Small tiles side by side in one wave (lane_columns_pack in ako_stream.hip.h): int16 levels of 8, 16, 32 or 64 coefficient
+// columns with an even width, any border rule but REPEAT, more than one tile in the group; returns the tiles per wave (0: no)
+uint32_t tile_pack(const akoHipPlan* pl, const Group& g, const LevelGeom& L, bool u8)
+{
+	if (!pl->tune.pack || u8 || pl->s.wrap == AKO_WRAP_REPEAT || g.tiles.size() < 2)
+		return 0;
+	if (L.tw < 8 || L.tw > 64 || (L.tw & (L.tw - 1)) != 0 || L.cw != 2 * L.tw || L.th < 2)
+		return 0;
+	// the lanes address their tile instance and their tile's stream with 32-bit byte offsets from the image's first
+	if (pl->stream_values * 2 >= 0xFFF00000ull || (uint64_t)g.tiles.size() * pl->channels * scratch_plane_elems(g, 0) * 2 >= 0xFFF00000ull)
+		return 0;
+	return 128u / L.tw;
+}
+
 // row slots a "deep prefetch" wave fetches up front and then works through (exactly that many, no loop):
 // segments of <= 6 rows + 6 halo slots, or of <= 2 rows
 constexpr int DEEP_SLOTS = 12, DEEP_SLOTS_SHORT = 8;
 
 // (groups != 0: the column-group kernel -- StreamGeom::strips then counts groups, waves_per_row_unit = 8 per tile instance)
-StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8, bool inverse, uint32_t groups = 0)
+// (pack != 0: that many small tiles side by side in one wave, lane_columns_pack; waves_per_row_unit then counts packs)
+StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8, bool inverse, uint32_t groups = 0,
+                           uint32_t pack = 0)
 {
 	StreamGeom G;
 	G.strips = groups ? groups : (L.tw + SNET - 1) / SNET;
@@ -477,6 +497,8 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 	// 121..128 coefficient columns (an even number): one strip without halo lanes instead of two
 	if (!groups && L.tw > (uint32_t)SNET && L.tw <= 128 && (L.tw & 1) == 0 && pl->tune.wide)
 		G.strips = 1, G.wide = 1;
+	if (pack)
+		G.strips = 1, G.wide = pack;
 	uint32_t seg_rows = (uint32_t)pl->tune.seg_rows;
 	if (pl->tune.seg_rows_big != 0 && L.tw >= 1024)  // tuning aid: levels with >= 1024 columns only
 		seg_rows = (uint32_t)pl->tune.seg_rows_big;
@@ -533,8 +555,6 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 	}
 	return G;
 }
-
-uint64_t scratch_plane_elems(const Group& g, int which);
 
 // Levels 0 and 1 of a u8 RGBA plan in one workgroup walk per direction (ako_fused.hip.h): shapes without a phantom
 // column or row at either level, the usual colour mode (YCoCg / YCoCg_Q without the discard rule), no REPEAT border (a
@@ -990,9 +1010,13 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
 				const bool grouped = u8 && grouped0;
+				// small tiles side by side in one wave: the tile instances of a launch then count in packs
+				// (not level 0 of a planar / staged plan: its source is the image, tile by tile, not a plane per tile instance)
+				const uint32_t pack = (grouped || l == 0) ? 0u : tile_pack(pl, g, L, u8);
+				const uint64_t pinsts = pack ? (uint64_t)packs_of((uint32_t)g.tiles.size(), pack) * pl->batch : insts;
 				const StreamGeom G = grouped ? stream_geometry(pl, L, (uint64_t)GRP_WAVES * insts, u8, false, group_count(L.tw))
-				                             : stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8, false);
-				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
+				                             : stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, false, 0, pack);
+				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * pinsts;
 				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.fwd_pairs : (uint32_t)(THREADS / 64);
 				const uint64_t blocks = grouped ? (uint64_t)G.strips * G.segs * insts : (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
@@ -1153,8 +1177,10 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 			{
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
-				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * insts, u8, true);
-				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * insts;
+				const uint32_t pack = (l == 0) ? 0u : tile_pack(pl, g, L, u8);
+				const uint64_t pinsts = pack ? (uint64_t)packs_of((uint32_t)g.tiles.size(), pack) * pl->batch : insts;
+				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, true, 0, pack);
+				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * pinsts;
 				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.inv_pairs : (uint32_t)(THREADS / 64);
 				const int deep = deep_prefetch(pl, G, u8);
 				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
@@ -1277,7 +1303,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.group, t.group_min, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.pack, t.group, t.group_min, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;

@@ -469,6 +469,12 @@ struct StreamGeom
 	uint32_t lockstep;
 };
 
+// packs of k tiles (StreamGeom::wide = k > 1: several small tiles side by side in one wave, see lane_columns_pack)
+__host__ __device__ __forceinline__ uint32_t packs_of(uint32_t n_tiles, uint32_t k)
+{
+	return (n_tiles + k - 1) / k;
+}
+
 // rows [r_lo, r_hi) of a segment and its nominal length
 __host__ __device__ __forceinline__ void segment_rows(const StreamGeom& G, uint32_t seg, int Tr, int& r_lo, int& r_hi, int& len)
 {
@@ -521,6 +527,13 @@ __device__ __forceinline__ void split_unit(T u, uint32_t blk, const LevelParams&
 	}
 	id.seg = (uint32_t)(u % (T)G.segs);
 	u /= (T)G.segs;
+	if (G.wide > 1)  // packed small tiles: the unit is a pack of G.wide consecutive tiles of the group
+	{
+		const T packs = (T)packs_of(P.n_tiles, G.wide);
+		id.tile = (uint32_t)(u % packs) * G.wide;
+		id.image = (uint32_t)(u / packs);
+		return;
+	}
 	id.tile = (uint32_t)(u % (T)P.n_tiles);
 	id.image = (uint32_t)(u / (T)P.n_tiles);
 }
@@ -540,7 +553,7 @@ __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const Stream
 	if (!(P.dbg & 4) && blk < (per_xcd << 3))
 		blk = (blk & 7) * per_xcd + (blk >> 3);
 	const uint64_t u = (uint64_t)blk * (blockDim.x >> 6) + wave;
-	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * P.n_tiles * P.batch;
+	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * (G.wide > 1 ? packs_of(P.n_tiles, G.wide) : P.n_tiles) * P.batch;
 	id.valid = u < total;
 	// 64-bit divisions are loops of several hundred scalar instructions each on this target -- a few microseconds of
 	// every wave's start, which the small levels (a wave there does ~1500 instructions of real work) feel; unit
@@ -583,6 +596,7 @@ struct LaneCols
 	bool hedge;
 	bool rot;  // odd level width: the four samples were fetched one sample early (see lane_columns)
 	bool net;  // this lane's columns belong to the strip's net range (it stores them)
+	int tile_in_pack;  // packed small tiles (lane_columns_pack): which of the wave's tiles this lane works on
 };
 
 // An ODD number of coefficient columns (level width = 2 mod 4) would leave the last column alone in the
@@ -629,6 +643,7 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	LaneCols lc;
 	const int c_base = strip_base_column(strip, strips, wide, Tc);
 	lc.c0 = c_base + 2 * lane;
+	lc.tile_in_pack = 0;
 	lc.net = wide || ((lane >= 2) && (lane < 62));
 	lc.he.wrap = wrap;
 	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
@@ -662,12 +677,43 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	return lc;
 }
 
+// SEVERAL SMALL TILES IN ONE WAVE (round 3).  A level of 8, 16, 32 or 64 coefficient columns would leave most of a
+// wave's 128 columns idle (16384 x 16384 in 256-pixel tiles: levels 1, 2, 3 use 50, 25, 12.5 % of their lanes).  Such a
+// level is a "wide" strip in miniature -- both its borders are tile borders, where nothing real lies beyond -- so k = 128 /
+// Tc tiles of one group sit side by side in one wave (StreamGeom::wide = k): lane l works on tile l / (Tc / 2), columns
+// 2 * (l % (Tc / 2)), +1; the taps across EVERY tile border come from border_values() in the tile's first / last lane,
+// exactly as a wide strip takes them (CLAMP, MIRROR, ZERO: per-lane values; REPEAT would need the other end of the
+// tile and stays unpacked); tile origin, stream offset and lift head become per-lane values.  int16 levels only (the
+// source of a packed level is the scratch plane of each tile instance, not the image).
+__device__ __forceinline__ LaneCols lane_columns_pack(int lane, int Tc, int wrap, int k_valid)
+{
+	LaneCols lc;
+	const int lpt = Tc >> 1;  // lanes per tile
+	lc.tile_in_pack = lane / lpt;
+	lc.c0 = 2 * (lane - lc.tile_in_pack * lpt);
+	lc.net = lc.tile_in_pack < k_valid;
+	lc.he.wrap = wrap;
+	lc.he.left = lc.he.right = false;
+	lc.he.nh_left = lc.he.nh_right = true;
+	lc.he.oob_l = lc.he.oob_r = false;
+	lc.he.lane_first = 0, lc.he.lane_last = 0;  // (only read for REPEAT and for out-of-range lanes: neither exists here)
+	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
+	lc.he.first = (lc.c0 == 0);
+	lc.he.last = (lc.c0 == Tc - 2);
+	lc.he.half = false, lc.he.drop_last = false;
+	lc.hedge = true;
+	lc.cs = lc.c0;
+	lc.rot = false;
+	lc.xs = 2 * lc.c0;
+	return lc;
+}
 // ---- helpers of the two-level workgroup kernels (ako_fused.hip.h) ----
 // lane_columns() for an arbitrary first column and net lane range (even Tc, no phantom column)
 __device__ __forceinline__ LaneCols lane_columns_at(int c_base, int net_lo, int net_hi, int lane, int Tc, int wrap)
 {
 	LaneCols lc;
 	lc.c0 = c_base + 2 * lane;
+	lc.tile_in_pack = 0;
 	lc.net = (lane >= net_lo) && (lane < net_hi);
 	lc.he.wrap = wrap;
 	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
@@ -1181,6 +1227,14 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	segment_rows(G, id.seg, Tr, r_lo, r_hi, seg_len);
 	(void)seg_len;
 
+	// Packed small tiles (lane_columns_pack, int16 levels only): the wave's resources are based at the IMAGE's first tile
+	// instance / at the image's stream, and the lane adds its own tile's instance and stream offset
+	constexpr bool CANPACK = !U8;
+	const bool pack = CANPACK && (G.wide > 1);
+	const uint32_t lane_tile = pack ? min(id.tile + (uint32_t)lc.tile_in_pack, P.n_tiles - 1u) : 0u;  // per lane
+	const uint64_t base_inst = pack ? (uint64_t)id.image * P.n_tiles : inst;                               // wave-uniform
+	const uint32_t lane_stream_b = pack ? (uint32_t)(P.tiles[lane_tile].stream_off * 2) : 0u;              // per lane
+
 	// Sources, read through a raw buffer resource like the stores below: the wave-uniform origin of the tile
 	// (plane) is the resource's base, the lane's four samples are ONE register of byte offset for every load of the
 	// wave, and the row travels as the scalar offset -- no 64-bit vector address arithmetic per row.  (All reads are
@@ -1194,7 +1248,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	}
 	else
 	{
-		const int16_t* src = P.src + ((P.src_tiled == 1) ? (uint64_t)id.image : inst) * P.src_inst_stride + (uint64_t)p_first * P.src_plane_stride;
+		const int16_t* src = P.src + ((P.src_tiled == 1) ? (uint64_t)id.image : base_inst) * P.src_inst_stride + (uint64_t)p_first * P.src_plane_stride;
 		if (P.src_tiled == 1)
 			src += (uint64_t)td.y0 * P.src_pitch + td.x0;
 		else if (P.src_tiled & 2)  // written by the column-group kernel: planes shifted to the phase of the stream's lines
@@ -1203,23 +1257,24 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		row_pitch_b = P.src_pitch * 2u;
 	}
 	const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_base), 0, (int)0xFFFFFFFFu, 0x00020000);
-	const uint32_t src_lane_off = (uint32_t)lc.xs * (U8 ? (uint32_t)CH : 2u);
+	const uint32_t src_lane_off = (uint32_t)lc.xs * (U8 ? (uint32_t)CH : 2u) + (pack ? lane_tile * (uint32_t)P.src_inst_stride * 2u : 0u);
 
 	// destinations.  Stream and LL stores go through raw buffer resources: a lane or a row that must not
 	// store gets an out-of-range offset and the hardware drops the write (scripts/probe_buffer_store.hip;
 	// 2-byte aligned dwords are fine there too).  Every row slot therefore issues the same 4 * NPL stores
 	// with no branch around them, which keeps the compiler's vmcnt bookkeeping exact: the wait in front of
 	// a slot's pixels no longer covers the stores of the previous slot (stores count in vmcnt on gfx950).
-	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+	const uint64_t tile_off = pack ? 0 : td.stream_off;  // (packed: the lane's tile offset travels in its byte offset)
+	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + tile_off;
 	const uint64_t nsub = (uint64_t)Tc * Tr;
 	const bool store_lane = lc.net && (c0 >= 0) && (c0 < Tc);
 	constexpr uint32_t OOB = 0xFFFFFFFFu;
 	constexpr int RSRC_FLAGS = 0x00020000;  // gfx9 raw buffer, 32 bit data format
-	const uint64_t stream_left = (P.stream_stride - td.stream_off) * 2;  // bytes up to the end of the image's stream
+	const uint64_t stream_left = (P.stream_stride - tile_off) * 2;  // bytes up to the end of the image's stream
 	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(
 	    tile_stream, 0, (int)(uint32_t)(stream_left < 0xFFFFFFFFull ? stream_left : 0xFFFFFFFFull), RSRC_FLAGS);
-	int16_t* ll_root = P.ll_out_stream ? tile_stream : (P.dst + inst * P.dst_inst_stride);
-	const uint64_t ll_left = P.ll_out_stream ? stream_left : (uint64_t)P.channels * P.dst_plane_stride * 2;
+	int16_t* ll_root = P.ll_out_stream ? tile_stream : (P.dst + base_inst * P.dst_inst_stride);
+	const uint64_t ll_left = P.ll_out_stream ? stream_left : (uint64_t)P.channels * P.dst_plane_stride * 2 * (pack ? P.n_tiles : 1u);
 	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(
 	    ll_root, 0, (int)(uint32_t)(ll_left < 0xFFFFFFFFull ? ll_left : 0xFFFFFFFFull), RSRC_FLAGS);
 	const uint32_t ll_pitch = P.ll_out_stream ? (uint32_t)Tc : P.dst_pitch;
@@ -1228,7 +1283,11 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 	// plane, sub-band, row -- is wave-uniform and travels as the scalar offset of the store, 0xFFFFFFFF for a row
 	// that must not be stored.  The hardware checks voffset + soffset (as a sum that does not wrap,
 	// scripts/probe_buffer_soffset.hip) against the end of the buffer.
-	const uint32_t lane_off = store_lane ? (uint32_t)(c0 * 2) : OOB;
+	const uint32_t lane_off = store_lane ? (uint32_t)(c0 * 2) + lane_stream_b : OOB;
+	// (packed: the low-pass plane of the lane's tile instance sits elsewhere than its stream: a second register; unpacked,
+	// and always on the u8 side, both are the same value)
+	const uint32_t lane_ll_off = !pack ? lane_off
+	                             : (store_lane ? (uint32_t)(c0 * 2) + (P.ll_out_stream ? lane_stream_b : lane_tile * (uint32_t)P.dst_inst_stride * 2u) : OOB);
 	uint32_t ll_off[NPL], grp_off[NPL];  // scalar: byte offset of column 0, row 0 of this plane's LL / C sub-band
 #pragma unroll
 	for (int p = 0; p < NPL; p++)
@@ -1254,11 +1313,11 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 			src_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(src_lane_off - lane16));
 	}
 
-	if (id.strip == 0 && id.seg == 0 && lane == 0)
+	if (pack ? (id.seg == 0 && lc.net && lc.he.first) : (id.strip == 0 && id.seg == 0 && lane == 0))  // the lift head of every tile
 #pragma unroll
 		for (int p = 0; p < NPL; p++)
 			if (!(one_plane && p == 1))
-				tile_stream[P.grp_off[p_first + p * P_STEP]] = (int16_t)((p_first + p * P_STEP == 0) ? P.q_luma : P.q_chroma);
+				(tile_stream + (lane_stream_b >> 1))[P.grp_off[p_first + p * P_STEP]] = (int16_t)((p_first + p * P_STEP == 0) ? P.q_luma : P.q_chroma);
 
 	const float gf_luma = (float)P.g_luma, gf_chroma = (float)P.g_chroma;
 
@@ -1522,7 +1581,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
 					const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
 					const uint32_t s_d = row_ok ? grp_off[p] + row_grp + 2u * nsub_b : OOB;
-					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, lane_off, s_ll, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(w_ll[p], rs_ll, lane_ll_off, s_ll, 0);
 					__builtin_amdgcn_raw_buffer_store_b32(w_c[p], rs_stream, lane_off, s_c, AUX_FWD_STREAM_STORE);
 					__builtin_amdgcn_raw_buffer_store_b32(w_b[p], rs_stream, lane_off, s_b, AUX_FWD_STREAM_STORE);
 					__builtin_amdgcn_raw_buffer_store_b32(w_d[p], rs_stream, lane_off, s_d, AUX_FWD_STREAM_STORE);
@@ -1596,7 +1655,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5))) vo
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = (!U8 && G.wide > 1) ? lane_columns_pack(lane, (int)P.sub_w, P.wrap, (int)min(G.wide, P.n_tiles - id.tile))
+	                                        : lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	// segment touches the top / bottom border (or wraps over it): needs the row boundary code
 	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	// u8 side: the usual colour mode gets straight-line pixel decoding (decode_pixels_ycocg)
@@ -1869,16 +1929,26 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	segment_rows(G, id.seg, Tr, r_lo, r_hi, seg_len);
 	(void)seg_len;
 
-	const int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+	// packed small tiles (lane_columns_pack, int16 levels only): resources based at the image's first tile instance / at the
+	// image's stream, the lane adds its own tile's instance and stream offset (and reads its own tile's lift head)
+	constexpr bool CANPACK = !U8;
+	const bool pack = CANPACK && (G.wide > 1);
+	const uint32_t lane_tile = pack ? min(id.tile + (uint32_t)lc.tile_in_pack, P.n_tiles - 1u) : 0u;  // per lane
+	const uint64_t base_inst = pack ? (uint64_t)id.image * P.n_tiles : inst;                               // wave-uniform
+	const uint32_t lane_stream_b = pack ? (uint32_t)(P.tiles[lane_tile].stream_off * 2) : 0u;              // per lane
+	const int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + (pack ? 0 : td.stream_off);
 	const uint64_t nsub = (uint64_t)Tc * Tr;
 	// Loads through raw buffer resources, as in the forward kernels: ONE register of byte offset per lane (its
 	// column pair) for every load of the wave; plane, sub-band and row travel as the scalar offset.
 	constexpr int RSRC_FLAGS = 0x00020000;
 	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(tile_stream), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
-	const int16_t* ll_root = P.ll_in_stream ? tile_stream : (P.src + inst * P.src_inst_stride);
+	const int16_t* ll_root = P.ll_in_stream ? tile_stream : (P.src + base_inst * P.src_inst_stride);
 	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(ll_root), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
 	const uint32_t ll_pitch = P.ll_in_stream ? (uint32_t)Tc : P.src_pitch;
-	const uint32_t lane_in_off = (uint32_t)lc.cs * 2u;
+	const uint32_t lane_in_off = (uint32_t)lc.cs * 2u + lane_stream_b;
+	// (packed: the low-pass plane of the lane's tile instance sits elsewhere than its stream: a second register)
+	const uint32_t lane_ll_in_off = !pack ? lane_in_off
+	                                : (uint32_t)lc.cs * 2u + (P.ll_in_stream ? lane_stream_b : lane_tile * (uint32_t)P.src_inst_stride * 2u);
 	const uint32_t nsub_b = (uint32_t)(nsub * 2);
 	uint32_t ll_off[NPL], grp_off[NPL];  // scalar: byte offset of column 0, row 0 of this plane's LL / C sub-band
 	int qv[NPL];
@@ -1886,7 +1956,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	for (int p = 0; p < NPL; p++)
 	{
 		const int pl = (one_plane && p == 1) ? p_first : p_first + p;  // (the absent plane: any valid offsets, never used)
-		qv[p] = tile_stream[P.grp_off[pl]];  // the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116)
+		qv[p] = (tile_stream + (lane_stream_b >> 1))[P.grp_off[pl]];  // the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116)
 		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1) * 2);
 		ll_off[p] = (uint32_t)((P.ll_in_stream ? P.lp_off[pl] : (uint64_t)pl * P.src_plane_stride) * 2);
 	}
@@ -1902,7 +1972,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	}
 	else
 	{
-		dst = P.dst + (P.dst_tiled ? (uint64_t)id.image : inst) * P.dst_inst_stride +
+		dst = P.dst + (P.dst_tiled ? (uint64_t)id.image : (base_inst + lane_tile)) * P.dst_inst_stride +
 		      (uint64_t)p_first * P.dst_plane_stride + 2 * c0;
 		if (P.dst_tiled)
 			dst += (uint64_t)td.y0 * P.dst_pitch + td.x0;
@@ -1954,7 +2024,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 				continue;
 			}
 			const uint32_t g = grp_off[p] + row_g;
-			raw.ll[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_ll, lane_in_off, ll_off[p] + row_l, 0);
+			raw.ll[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_ll, lane_ll_in_off, ll_off[p] + row_l, 0);
 			raw.c[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g, AUX_INV_STREAM_LOAD);
 			raw.b[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + nsub_b, AUX_INV_STREAM_LOAD);
 			raw.d[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + 2u * nsub_b, AUX_INV_STREAM_LOAD);
@@ -2244,7 +2314,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	if (!id.valid)
 		return;  // U8: units come in pairs and the workgroup is one pair, so both waves leave together
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = (!U8 && G.wide > 1) ? lane_columns_pack(lane, (int)P.sub_w, P.wrap, (int)min(G.wide, P.n_tiles - id.tile))
+	                                        : lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	if (lc.hedge)
 	{
