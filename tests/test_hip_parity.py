@@ -408,6 +408,49 @@ def test_column_groups_at_level_0(po):
     assert n_grouped >= 30, n_grouped
 
 
+def test_small_tiles_packed_into_waves(po):
+    """Levels of 8, 16, 32 or 64 coefficient columns of a tiled image run SEVERAL tiles side by side in one wave (lane_columns_pack:
+    every tile border inside the wave takes its taps from the border rule, tile origin / stream offset / lift head are per-lane
+    values).  Tile counts that leave the last wave partly filled, groups of edge tiles of other sizes (packed among themselves
+    or, a single one, not at all), every border rule (REPEAT stays unpacked), all wavelets, 1-4 channels, quantizers that
+    differ per level, batches -- streams byte-for-byte against the oracle, decoded pixels bit-exact, with the packing on and
+    off."""
+    nrng = np.random.default_rng(4242)
+    cases = [(5 * 32 + 9, 3 * 32 + 5, 32), (7 * 64, 2 * 64 + 17, 64), (3 * 128 + 40, 128, 128), (11 * 16 + 3, 5 * 16, 16), (9 * 256 // 3, 256 + 31, 256),
+             (640, 384, 128), (1000, 300, 64), (520, 520, 256), (96, 800, 32), (2048, 256, 256)]
+    for path in ("auto", "stream"):
+        for ci, (w, h, tiles) in enumerate(cases):
+            for wavelet in (0, 1, 2):
+                ch = int(nrng.choice([4, 4, 3, 1, 2]))
+                wrap = int(nrng.integers(0, 4))
+                q = int(nrng.choice([0, 1, 7, 16, 40]))
+                g = int(nrng.choice([0, 0, 5, 16]))
+                color = int(nrng.choice([0, 0, 1, 2, 3]))
+                batch = 2 if ci % 3 == 0 else 1
+                imgs = [nrng.integers(0, 256, (h, w, ch), dtype=np.uint8) if nrng.random() < 0.5
+                        else np.ascontiguousarray(po.gen_image(0, w, h, int(nrng.integers(1, 1 << 30)))[:, :, :ch]) for _ in range(batch)]
+                s = po.settings(wavelet=wavelet, wrap=wrap, color=color, compression=2, q=q, g=g, tiles=tiles)
+                blobs = []
+                for img in imgs:
+                    ob, st = po.encode_image(s, img)
+                    assert st == 0
+                    blobs.append(ob)
+                s.color = po.effective_color(s)
+                for pack in (1, 0):
+                    with _with_env(dict(AKO_HIP_PATH=path, AKO_HIP_PACK=pack)):
+                        with api.Plan(_to_api(s), ch, w, h, batch=batch) as plan:
+                            d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).cuda())
+                            d_back = plan.decode(d_streams)
+                            plan.synchronize()
+                            bodies = d_streams.cpu().numpy().reshape(batch, -1).view(np.uint8)
+                            back = d_back.cpu().numpy().reshape(batch, h, w, ch)
+                    tag = (path, w, h, tiles, wavelet, wrap, ch, color, q, g, pack)
+                    for k in range(batch):
+                        assert np.array_equal(bodies[k], blobs[k][16:]), (tag, k)
+                        od, _, _ = po.decode_image(blobs[k])
+                        assert np.array_equal(back[k], od), (tag, k)
+
+
 def test_shipped_library_ignores_the_measurement_switch(po):
     """AKO_HIP_DBG selects measurement kernels (loads / stores without arithmetic: garbage output) in -DAKO_MEASURE
     builds only.  The shipped library neither holds those kernels nor reads the variable: with every bit set it must still
