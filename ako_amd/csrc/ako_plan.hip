@@ -70,6 +70,7 @@ struct Group
 	uint64_t tile_values = 0;  // int16 per tile stream
 	std::vector<TileDesc> tiles;
 	TileDesc* d_tiles = nullptr;
+	uint32_t row_tiles = 0;  // tiles per tile row when the group's tiles form full rows of horizontally adjacent tiles (0: they do not)
 };
 
 struct TileInfo
@@ -144,6 +145,7 @@ struct Tuning
 	int fuse2 = 0;         // AKO_HIP_FUSE2: levels 0 and 1 of eligible RGBA plans in one workgroup walk, the level-0 low-pass plane
 	                       // handed over through LDS (ako_fused.hip.h): bit 0 forward, bit 1 inverse.  Bit-exact and parity-tested,
 	                       // off by default: measured slower than the level-per-kernel launches
+	int row_strips = 1;    // AKO_HIP_ROW_STRIPS: level 0 of u8 images in 512-pixel tiles in strips over whole rows of tiles (0: per tile)
 	int pack = 1;          // AKO_HIP_PACK: levels of 8..64 columns of tiled images run several tiles per wave (0: one tile per wave)
 	int group = 0;         // AKO_HIP_GROUP: level 0 of big RGBA tiles in column groups, the stores re-shaped into whole cache lines
 	                       // (k_forward_group_u8, ako_stream.hip.h).  Bit-exact and parity-tested, off by default: the level-0
@@ -189,6 +191,7 @@ struct Tuning
 			t.inv_pairs = 2;
 		t.fuse2 = num("AKO_HIP_FUSE2", 0) & 3;
 		t.pack = num("AKO_HIP_PACK", 1) != 0;
+		t.row_strips = num("AKO_HIP_ROW_STRIPS", 1) != 0;
 		t.group = num("AKO_HIP_GROUP", 0);
 		t.group_min = num("AKO_HIP_GROUP_MIN", 1024);
 		t.f2_rows = num("AKO_HIP_F2_ROWS", 0);
@@ -481,6 +484,22 @@ uint32_t tile_pack(const akoHipPlan* pl, const Group& g, const LevelGeom& L, boo
 	return 128u / L.tw;
 }
 
+// Level 0 of a u8 image in strips laid over whole ROWS of tiles (lane_columns_row in ako_stream.hip.h): tiles wider than one
+// wide strip (more than 128 coefficient columns: 512-pixel tiles), at least two per row, an even level width, any border
+// rule but REPEAT; returns the tiles per row (0: no)
+uint32_t row_strips(const akoHipPlan* pl, const Group& g, const LevelGeom& L, bool u8)
+{
+	if (!pl->tune.row_strips || !u8 || pl->s.wrap == AKO_WRAP_REPEAT || g.row_tiles < 2 || g.row_tiles > 0xFFFF)
+		return 0;
+	if (L.tw <= 128 || (L.tw & 1) != 0 || L.cw != 2 * L.tw)
+		return 0;
+	if (pl->stream_values * 2 >= 0xFFF00000ull || (uint64_t)g.tiles.size() * pl->channels * scratch_plane_elems(g, 0) * 2 >= 0xFFF00000ull)
+		return 0;
+	// only where it saves strips
+	const uint32_t per_tile = (L.tw + SNET - 1) / SNET, per_row = (g.row_tiles * L.tw + SNET - 1) / SNET;
+	return (per_row < per_tile * g.row_tiles) ? g.row_tiles : 0u;
+}
+
 // row slots a "deep prefetch" wave fetches up front and then works through (exactly that many, no loop):
 // segments of <= 6 rows + 6 halo slots, or of <= 2 rows
 constexpr int DEEP_SLOTS = 12, DEEP_SLOTS_SHORT = 8;
@@ -488,7 +507,7 @@ constexpr int DEEP_SLOTS = 12, DEEP_SLOTS_SHORT = 8;
 // (groups != 0: the column-group kernel -- StreamGeom::strips then counts groups, waves_per_row_unit = 8 per tile instance)
 // (pack != 0: that many small tiles side by side in one wave, lane_columns_pack; waves_per_row_unit then counts packs)
 StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t waves_per_row_unit, bool u8, bool inverse, uint32_t groups = 0,
-                           uint32_t pack = 0)
+                           uint32_t pack = 0, uint32_t row_tiles = 0)
 {
 	StreamGeom G;
 	G.strips = groups ? groups : (L.tw + SNET - 1) / SNET;
@@ -500,6 +519,8 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		G.strips = 1, G.wide = 1;
 	if (pack)
 		G.strips = 1, G.wide = pack;
+	if (row_tiles)  // strips over a whole row of tiles (waves_per_row_unit then counts tile ROWS)
+		G.strips = (row_tiles * L.tw + SNET - 1) / SNET, G.wide = 0x80000000u | row_tiles;
 	uint32_t seg_rows = (uint32_t)pl->tune.seg_rows;
 	if (pl->tune.seg_rows_big != 0 && L.tw >= 1024)  // tuning aid: levels with >= 1024 columns only
 		seg_rows = (uint32_t)pl->tune.seg_rows_big;
@@ -512,7 +533,11 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 		// rows; small levels are latency bound (a wave's row slots are a dependent chain) and prefer many
 		// short segments.  Rounded DOWN: a handful of waves over the target would cost a third round
 		const uint64_t per_seg = (uint64_t)G.strips * waves_per_row_unit;
-		uint64_t segs = (u8 ? (uint64_t)(pl->tune.u8_waves > 0 ? pl->tune.u8_waves : 8192) : 10240) / per_seg;
+		// (row strips over many tile rows: one segment per tile row would be a little more than ONE round of resident waves --
+		// 4416 for 16384 x 16384 in 512-pixel tiles -- whose stragglers run alone; five rounds of shorter segments instead:
+		// 256 -> 64 rows, level 0 1.22 / 1.11 -> 0.98 / 0.84 ms)
+		const uint64_t u8_target = row_tiles ? 5 * 4096 : 8192;
+		uint64_t segs = (u8 ? (uint64_t)(pl->tune.u8_waves > 0 ? pl->tune.u8_waves : u8_target) : 10240) / per_seg;
 		if (segs < 1)
 			segs = 1;
 		seg_rows = (uint32_t)((L.th + segs - 1) / segs);
@@ -1014,9 +1039,12 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				// small tiles side by side in one wave: the tile instances of a launch then count in packs
 				// (not level 0 of a planar / staged plan: its source is the image, tile by tile, not a plane per tile instance)
 				const uint32_t pack = (grouped || l == 0) ? 0u : tile_pack(pl, g, L, u8);
-				const uint64_t pinsts = pack ? (uint64_t)packs_of((uint32_t)g.tiles.size(), pack) * pl->batch : insts;
+				const uint32_t rowt = (grouped || l != 0) ? 0u : row_strips(pl, g, L, u8);
+				const uint64_t pinsts = pack   ? (uint64_t)packs_of((uint32_t)g.tiles.size(), pack) * pl->batch
+				                        : rowt ? (uint64_t)(g.tiles.size() / rowt) * pl->batch
+				                               : insts;
 				const StreamGeom G = grouped ? stream_geometry(pl, L, (uint64_t)GRP_WAVES * insts, u8, false, group_count(L.tw))
-				                             : stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, false, 0, pack);
+				                             : stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, false, 0, pack, rowt);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * pinsts;
 				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.fwd_pairs : (uint32_t)(THREADS / 64);
 				const uint64_t blocks = grouped ? (uint64_t)G.strips * G.segs * insts : (units + waves_per_block - 1) / waves_per_block;
@@ -1179,8 +1207,11 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
 				const uint32_t pack = (l == 0) ? 0u : tile_pack(pl, g, L, u8);
-				const uint64_t pinsts = pack ? (uint64_t)packs_of((uint32_t)g.tiles.size(), pack) * pl->batch : insts;
-				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, true, 0, pack);
+				const uint32_t rowt = (l != 0 || f2inv) ? 0u : row_strips(pl, g, L, u8);
+				const uint64_t pinsts = pack   ? (uint64_t)packs_of((uint32_t)g.tiles.size(), pack) * pl->batch
+				                        : rowt ? (uint64_t)(g.tiles.size() / rowt) * pl->batch
+				                               : insts;
+				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, true, 0, pack, rowt);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * pinsts;
 				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.inv_pairs : (uint32_t)(THREADS / 64);
 				const int deep = deep_prefetch(pl, G, u8);
@@ -1304,7 +1335,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.pack, t.group, t.group_min, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.pack, t.row_strips, t.group, t.group_min, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;
@@ -1421,6 +1452,17 @@ akoHipPlan* akoHipPlanCreate(int device, const struct akoSettings* settings, siz
 
 		for (Group& g : pl->groups)
 		{
+			// rows of horizontally adjacent tiles, all rows equally long, in raster order (the interior group, the bottom edge)
+			{
+				size_t ntx = 1;
+				while (ntx < g.tiles.size() && g.tiles[ntx].y0 == g.tiles[0].y0)
+					ntx++;
+				bool ok = ntx >= 2 && g.tiles.size() % ntx == 0;
+				for (size_t i = 0; ok && i < g.tiles.size(); i++)
+					ok = (i % ntx == 0) ? (g.tiles[i].x0 == g.tiles[0].x0 && (i == 0 || g.tiles[i].y0 > g.tiles[i - ntx].y0))
+					                    : (g.tiles[i].y0 == g.tiles[i - 1].y0 && g.tiles[i].x0 == g.tiles[i - 1].x0 + g.tile_w);
+				g.row_tiles = ok ? (uint32_t)ntx : 0u;
+			}
 			if (hipMalloc((void**)&g.d_tiles, g.tiles.size() * sizeof(TileDesc)) != hipSuccess)
 				PLAN_FAIL(AKO_NO_ENOUGH_MEMORY, "hipMalloc(tile table) failed");
 			if (hipMemcpy(g.d_tiles, g.tiles.data(), g.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice) !=

@@ -527,10 +527,11 @@ __device__ __forceinline__ void split_unit(T u, uint32_t blk, const LevelParams&
 	}
 	id.seg = (uint32_t)(u % (T)G.segs);
 	u /= (T)G.segs;
-	if (G.wide > 1)  // packed small tiles: the unit is a pack of G.wide consecutive tiles of the group
+	if (G.wide > 1)  // packed small tiles / row strips: the unit is a pack of consecutive tiles of the group / a row of them
 	{
-		const T packs = (T)packs_of(P.n_tiles, G.wide);
-		id.tile = (uint32_t)(u % packs) * G.wide;
+		const uint32_t k = (G.wide >> 31) ? (G.wide & 0xFFFFu) : G.wide;
+		const T packs = (T)packs_of(P.n_tiles, k);
+		id.tile = (uint32_t)(u % packs) * k;
 		id.image = (uint32_t)(u / packs);
 		return;
 	}
@@ -553,7 +554,7 @@ __device__ __forceinline__ UnitId decode_unit(const LevelParams& P, const Stream
 	if (!(P.dbg & 4) && blk < (per_xcd << 3))
 		blk = (blk & 7) * per_xcd + (blk >> 3);
 	const uint64_t u = (uint64_t)blk * (blockDim.x >> 6) + wave;
-	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * (G.wide > 1 ? packs_of(P.n_tiles, G.wide) : P.n_tiles) * P.batch;
+	const uint64_t total = (uint64_t)G.strips * G.segs * P.plane_groups * (G.wide > 1 ? packs_of(P.n_tiles, (G.wide >> 31) ? (G.wide & 0xFFFFu) : G.wide) : P.n_tiles) * P.batch;
 	id.valid = u < total;
 	// 64-bit divisions are loops of several hundred scalar instructions each on this target -- a few microseconds of
 	// every wave's start, which the small levels (a wave there does ~1500 instructions of real work) feel; unit
@@ -685,6 +686,52 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 // exactly as a wide strip takes them (CLAMP, MIRROR, ZERO: per-lane values; REPEAT would need the other end of the
 // tile and stays unpacked); tile origin, stream offset and lift head become per-lane values.  int16 levels only (the
 // source of a packed level is the scratch plane of each tile instance, not the image).
+// StreamGeom::wide: 0 ordinary strips; 1 one wide strip; 2..64 that many small tiles per wave (int16 levels); bit 31 set:
+// ROW STRIPS over the tiles of a tile row, low 16 bits = tiles per row (u8 level 0, below)
+__host__ __device__ __forceinline__ bool geom_wide(const StreamGeom& G)
+{
+	return G.wide == 1u;
+}
+__host__ __device__ __forceinline__ uint32_t geom_pack(const StreamGeom& G)
+{
+	return (G.wide > 1u && !(G.wide >> 31)) ? G.wide : 0u;
+}
+__host__ __device__ __forceinline__ uint32_t geom_row_tiles(const StreamGeom& G)
+{
+	return (G.wide >> 31) ? (G.wide & 0xFFFFu) : 0u;
+}
+
+// ROW STRIPS (round 3): level 0 of a u8 image in 512-pixel tiles has 256 coefficient columns per tile -- three strips of
+// 120, the third one for 16 columns.  The tiles of a tile row lie side by side in the image, so the strips are laid over
+// the whole ROW of tiles instead (ntx * Tc columns, 120 net each: 69 strips for 32 tiles instead of 96): a lane's pixels
+// are just the image columns it covers, its tile is (global column) / Tc, and a tile border that falls inside a strip is
+// handled where it falls, through border_values() in the tile's first / last lane, as in a wide strip or a pack of small
+// tiles.  Stream offset, low-pass plane and lift head are per-lane values.  Not for REPEAT.
+__device__ __forceinline__ LaneCols lane_columns_row(uint32_t strip, int lane, int Tc, int ntx, int wrap)
+{
+	LaneCols lc;
+	const int total = ntx * Tc;
+	const int gcol = (int)strip * SNET - SORG + 2 * lane;  // column inside the row of tiles (even)
+	const int gin = min(max(gcol, 0), total - 2);           // ... clamped into it for the loads of the halo lanes at the two ends
+	lc.tile_in_pack = gin / Tc;
+	lc.c0 = gin - lc.tile_in_pack * Tc;
+	lc.net = (lane >= 2) && (lane < 62) && (gcol >= 0) && (gcol < total);
+	lc.he.wrap = wrap;
+	lc.he.left = lc.he.right = false;
+	lc.he.nh_left = lc.he.nh_right = true;
+	lc.he.oob_l = lc.he.oob_r = false;
+	lc.he.lane_first = 0, lc.he.lane_last = 0;
+	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
+	lc.he.first = (lc.c0 == 0);
+	lc.he.last = (lc.c0 == Tc - 2);
+	lc.he.half = false, lc.he.drop_last = false;
+	lc.hedge = true;
+	lc.cs = lc.c0;
+	lc.rot = false;
+	lc.xs = 2 * gin;  // the image side: samples counted from the row's first tile
+	return lc;
+}
+
 __device__ __forceinline__ LaneCols lane_columns_pack(int lane, int Tc, int wrap, int k_valid)
 {
 	LaneCols lc;
@@ -1229,8 +1276,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 
 	// Packed small tiles (lane_columns_pack, int16 levels only): the wave's resources are based at the IMAGE's first tile
 	// instance / at the image's stream, and the lane adds its own tile's instance and stream offset
-	constexpr bool CANPACK = !U8;
-	const bool pack = CANPACK && (G.wide > 1);
+	const bool pack = U8 ? (geom_row_tiles(G) != 0) : (geom_pack(G) != 0);  // (u8: row strips over a row of tiles)
 	const uint32_t lane_tile = pack ? min(id.tile + (uint32_t)lc.tile_in_pack, P.n_tiles - 1u) : 0u;  // per lane
 	const uint64_t base_inst = pack ? (uint64_t)id.image * P.n_tiles : inst;                               // wave-uniform
 	const uint32_t lane_stream_b = pack ? (uint32_t)(P.tiles[lane_tile].stream_off * 2) : 0u;              // per lane
@@ -1257,7 +1303,7 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		row_pitch_b = P.src_pitch * 2u;
 	}
 	const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_base), 0, (int)0xFFFFFFFFu, 0x00020000);
-	const uint32_t src_lane_off = (uint32_t)lc.xs * (U8 ? (uint32_t)CH : 2u) + (pack ? lane_tile * (uint32_t)P.src_inst_stride * 2u : 0u);
+	const uint32_t src_lane_off = (uint32_t)lc.xs * (U8 ? (uint32_t)CH : 2u) + ((!U8 && pack) ? lane_tile * (uint32_t)P.src_inst_stride * 2u : 0u);
 
 	// destinations.  Stream and LL stores go through raw buffer resources: a lane or a row that must not
 	// store gets an out-of-range offset and the hardware drops the write (scripts/probe_buffer_store.hip;
@@ -1655,8 +1701,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5))) vo
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = (!U8 && G.wide > 1) ? lane_columns_pack(lane, (int)P.sub_w, P.wrap, (int)min(G.wide, P.n_tiles - id.tile))
-	                                        : lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = (!U8 && geom_pack(G)) ? lane_columns_pack(lane, (int)P.sub_w, P.wrap, (int)min(geom_pack(G), P.n_tiles - id.tile))
+	                                        : lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	// segment touches the top / bottom border (or wraps over it): needs the row boundary code
 	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	// u8 side: the usual colour mode gets straight-line pixel decoding (decode_pixels_ycocg)
@@ -1718,7 +1764,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream_u8_memonly(const Lev
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	forward_stream_body<K_DD137, 2, true, false, false, true, 0, true, 2, U8_RING, true>(P, G, id, lc, lane);
 }
 
@@ -1729,7 +1775,7 @@ __global__ __launch_bounds__(THREADS) void k_forward_stream_i16_memonly(const Le
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	forward_stream_body<K_DD137, 1, false, false, false, true, 0, false, 2, 0, true>(P, G, id, lc, lane);
 }
 #endif  // AKO_MEASURE
@@ -1741,7 +1787,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const uint32_t row_tiles = geom_row_tiles(G);
+	const LaneCols lc = row_tiles ? lane_columns_row(id.strip, lane, (int)P.sub_w, (int)min(row_tiles, P.n_tiles - id.tile), P.wrap)
+	                              : lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	// the usual colour mode gets straight-line pixel decoding (decode_pixels_ycocg)
 	const bool cfast = (P.color == C_YCOCG || P.color == C_YCOCG_Q) && P.discard == 0;
@@ -1931,8 +1979,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 
 	// packed small tiles (lane_columns_pack, int16 levels only): resources based at the image's first tile instance / at the
 	// image's stream, the lane adds its own tile's instance and stream offset (and reads its own tile's lift head)
-	constexpr bool CANPACK = !U8;
-	const bool pack = CANPACK && (G.wide > 1);
+	const bool pack = U8 ? (geom_row_tiles(G) != 0) : (geom_pack(G) != 0);  // (u8: row strips over a row of tiles)
 	const uint32_t lane_tile = pack ? min(id.tile + (uint32_t)lc.tile_in_pack, P.n_tiles - 1u) : 0u;  // per lane
 	const uint64_t base_inst = pack ? (uint64_t)id.image * P.n_tiles : inst;                               // wave-uniform
 	const uint32_t lane_stream_b = pack ? (uint32_t)(P.tiles[lane_tile].stream_off * 2) : 0u;              // per lane
@@ -1985,7 +2032,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 	// that is out of range in a lane that must not store, the row is the scalar offset (0xFFFFFFFF: row dropped)
 	constexpr uint32_t OOB = 0xFFFFFFFFu;
 	const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(U8 ? (void*)img : (void*)nullptr, 0, U8 ? (int)0xFFFFFFFFu : 0, RSRC_FLAGS);
-	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * c0) * (uint32_t)CH : OOB;
+	const int img_c0 = (U8 && pack) ? (lc.xs >> 1) : c0;  // row strips: the lane's column inside the row of tiles
+	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * img_c0) * (uint32_t)CH : OOB;
 	(void)rs_img, (void)px_lane_off;
 
 	VInv<V> st[NPL][4];
@@ -2224,7 +2272,7 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 						px[k] = (uint32_t)sat8(rr) | ((uint32_t)sat8(gg) << 8) | ((uint32_t)sat8(bb) << 16) |
 						        ((CH == 3) ? 0u : ((uint32_t)sat8((int)v3) << 24));
 					}
-					uint8_t* row = img + (uint64_t)y * out_pitch + (int64_t)(2 * c0) * CH;
+					uint8_t* row = img + (uint64_t)y * out_pitch + (int64_t)(2 * img_c0) * CH;
 					if constexpr (CH == 3)
 					{
 						const auto w3 = rgb_pack4(px);
@@ -2314,8 +2362,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	if (!id.valid)
 		return;  // U8: units come in pairs and the workgroup is one pair, so both waves leave together
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = (!U8 && G.wide > 1) ? lane_columns_pack(lane, (int)P.sub_w, P.wrap, (int)min(G.wide, P.n_tiles - id.tile))
-	                                        : lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = (!U8 && geom_pack(G)) ? lane_columns_pack(lane, (int)P.sub_w, P.wrap, (int)min(geom_pack(G), P.n_tiles - id.tile))
+	                                        : lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	if (lc.hedge)
 	{
@@ -2356,7 +2404,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	if (!id.valid)
 		return;  // units come in pairs, so both waves of a pair leave together (a barrier does not wait for ended waves)
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const uint32_t row_tiles = geom_row_tiles(G);
+	const LaneCols lc = row_tiles ? lane_columns_row(id.strip, lane, (int)P.sub_w, (int)min(row_tiles, P.n_tiles - id.tile), P.wrap)
+	                              : lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	if (__builtin_expect(vedge, 0))
 	{
@@ -2383,7 +2433,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide != 0, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	inverse_stream_body<K_DD137, 2, true, true, false, true, 0, 2, true>(P, G, id, lc, lane, nullptr);
 }
 #endif  // AKO_MEASURE
