@@ -484,19 +484,21 @@ uint32_t tile_pack(const akoHipPlan* pl, const Group& g, const LevelGeom& L, boo
 	return 128u / L.tw;
 }
 
-// Level 0 of a u8 image in strips laid over whole ROWS of tiles (lane_columns_row in ako_stream.hip.h): tiles wider than one
-// wide strip (more than 128 coefficient columns: 512-pixel tiles), at least two per row, an even level width, any border
-// rule but REPEAT; returns the tiles per row (0: no)
+// Level 0 of a u8 image in strips laid over whole ROWS of tiles (lane_columns_row in ako_stream.hip.h): at least two tiles per
+// row, an even level width, any border rule but REPEAT, and fewer strips than tile by tile (512-pixel tiles: 256 columns
+// = three strips each; tiles of 128 pixels and less: a quarter to half a strip each; not 256-pixel tiles, which are exactly
+// one wide strip); returns the tiles per row (0: no)
 uint32_t row_strips(const akoHipPlan* pl, const Group& g, const LevelGeom& L, bool u8)
 {
 	if (!pl->tune.row_strips || !u8 || pl->s.wrap == AKO_WRAP_REPEAT || g.row_tiles < 2 || g.row_tiles > 0xFFFF)
 		return 0;
-	if (L.tw <= 128 || (L.tw & 1) != 0 || L.cw != 2 * L.tw)
+	if (L.tw < 4 || (L.tw & 1) != 0 || L.cw != 2 * L.tw)
 		return 0;
 	if (pl->stream_values * 2 >= 0xFFF00000ull || (uint64_t)g.tiles.size() * pl->channels * scratch_plane_elems(g, 0) * 2 >= 0xFFF00000ull)
 		return 0;
 	// only where it saves strips
-	const uint32_t per_tile = (L.tw + SNET - 1) / SNET, per_row = (g.row_tiles * L.tw + SNET - 1) / SNET;
+	const bool one_wide = L.tw > (uint32_t)SNET && L.tw <= 128 && pl->tune.wide;  // (a tile of 121..128 columns is ONE wide strip)
+	const uint32_t per_tile = one_wide ? 1u : (L.tw + SNET - 1) / SNET, per_row = (g.row_tiles * L.tw + SNET - 1) / SNET;
 	return (per_row < per_tile * g.row_tiles) ? g.row_tiles : 0u;
 }
 
@@ -1038,7 +1040,8 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				const bool grouped = u8 && grouped0;
 				// small tiles side by side in one wave: the tile instances of a launch then count in packs
 				// (not level 0 of a planar / staged plan: its source is the image, tile by tile, not a plane per tile instance)
-				const uint32_t pack = (grouped || l == 0) ? 0u : tile_pack(pl, g, L, u8);
+				// (nor level 1 behind a column-group level 0: its low-pass planes are shifted by a phase that differs per tile)
+				const uint32_t pack = (grouped || l == 0 || (l == 1 && grouped0)) ? 0u : tile_pack(pl, g, L, u8);
 				const uint32_t rowt = (grouped || l != 0) ? 0u : row_strips(pl, g, L, u8);
 				const uint64_t pinsts = pack   ? (uint64_t)packs_of((uint32_t)g.tiles.size(), pack) * pl->batch
 				                        : rowt ? (uint64_t)(g.tiles.size() / rowt) * pl->batch

@@ -451,6 +451,49 @@ def test_small_tiles_packed_into_waves(po):
                         assert np.array_equal(back[k], od), (tag, k)
 
 
+def test_row_strips_over_rows_of_512_pixel_tiles(po):
+    """Level 0 of a u8 image in 512-pixel tiles (256 coefficient columns per tile) runs in strips laid over whole ROWS of tiles
+    (lane_columns_row): tile borders fall at any lane of a strip, stream offset / low-pass plane / lift head are per-lane
+    values.  Two to five tiles per row, interior + right-edge + bottom-edge + corner groups (the bottom edge is a row of tiles
+    too, the right edge never), every border rule (REPEAT stays per tile), both wavelets and Haar, RGBA and RGB, batches, short
+    and long row segments -- streams byte-for-byte against the oracle, decoded pixels bit-exact, with the row strips on and off."""
+    nrng = np.random.default_rng(99)
+    cases = [(1024, 512), (1024 + 200, 512 + 100), (1536, 1100), (2048 + 36, 520), (2560, 96), (1028, 1024 + 8)]
+    knobs = [{}, {"AKO_HIP_SEG_ROWS": 6}, {"AKO_HIP_SEG_ROWS": 40}]
+    for path in ("auto", "stream"):
+        for ci, (w, h) in enumerate(cases):
+            for wavelet in (0, 1, 2):
+                ch = 4 if (ci + wavelet) % 3 else 3
+                wrap = int(nrng.integers(0, 4))
+                q = int(nrng.choice([0, 1, 7, 16, 40]))
+                g = int(nrng.choice([0, 0, 5, 16]))
+                color = int(nrng.choice([0, 0, 0, 1, 2, 3]))
+                batch = 2 if ci % 2 == 0 else 1
+                imgs = [nrng.integers(0, 256, (h, w, ch), dtype=np.uint8) if nrng.random() < 0.5
+                        else np.ascontiguousarray(po.gen_image(0, w, h, int(nrng.integers(1, 1 << 30)))[:, :, :ch]) for _ in range(batch)]
+                s = po.settings(wavelet=wavelet, wrap=wrap, color=color, compression=2, q=q, g=g, tiles=512)
+                blobs = []
+                for img in imgs:
+                    ob, st = po.encode_image(s, img)
+                    assert st == 0
+                    blobs.append(ob)
+                s.color = po.effective_color(s)
+                for rows in (1, 0):
+                    env = dict(knobs[(ci + wavelet) % len(knobs)], AKO_HIP_PATH=path, AKO_HIP_ROW_STRIPS=rows)
+                    with _with_env(env):
+                        with api.Plan(_to_api(s), ch, w, h, batch=batch) as plan:
+                            d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).cuda())
+                            d_back = plan.decode(d_streams)
+                            plan.synchronize()
+                            bodies = d_streams.cpu().numpy().reshape(batch, -1).view(np.uint8)
+                            back = d_back.cpu().numpy().reshape(batch, h, w, ch)
+                    tag = (path, w, h, wavelet, wrap, ch, color, q, g, env)
+                    for k in range(batch):
+                        assert np.array_equal(bodies[k], blobs[k][16:]), (tag, k)
+                        od, _, _ = po.decode_image(blobs[k])
+                        assert np.array_equal(back[k], od), (tag, k)
+
+
 def test_shipped_library_ignores_the_measurement_switch(po):
     """AKO_HIP_DBG selects measurement kernels (loads / stores without arithmetic: garbage output) in -DAKO_MEASURE
     builds only.  The shipped library neither holds those kernels nor reads the variable: with every bit set it must still
