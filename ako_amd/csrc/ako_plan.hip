@@ -135,9 +135,9 @@ struct Tuning
 	int seg_rows_mid = 0, seg_rows_mid_inv = 0;  // AKO_HIP_SEG_ROWS_MID / _MID_INV: same for int16 levels of 1024..2047
 	                                             // columns, forward / inverse kernels
 	int floor_big = 24;    // AKO_HIP_FLOOR_BIG: fewest rows per segment of levels with >= 2048 columns
-	int tail_many = 8;     // AKO_HIP_TAIL_MANY: largest level the tail takes when a launch has many planes (tiled images;
+	int tail_many = 4;     // AKO_HIP_TAIL_MANY: largest level the tail takes when a launch has many planes (tiled images;
 	                       // 16384 x 16384 in 256-px tiles, round 2: 8 -> 89, 16 -> 95, 32 -> 90, 64 -> 51 Gpx/s; round 3, with
-	                       // several small tiles per wave in the streaming kernels: 16 -> 116-118, 8 -> 119.4)
+	                       // several small tiles per wave in the streaming kernels: 16 -> 116-118, 8 -> 119.4-122, 4 -> 123-128)
 	int u8_waves = 0;      // AKO_HIP_U8_WAVES: waves a u8 level launch aims at (0 = two rounds of resident waves)
 	int lockstep = 3;      // AKO_HIP_LOCKSTEP: StreamGeom::lockstep (bit 0 barrier every six slots, bit 1 strip-major units)
 	int fwd_pairs = 2;     // AKO_HIP_FWD_PAIRS: pairs of waves (= neighbouring strips) per workgroup of the u8 forward kernel
@@ -174,9 +174,9 @@ struct Tuning
 		t.staged = num("AKO_HIP_STAGED", 1);
 		t.deep = num("AKO_HIP_DEEP", 1) != 0;
 		t.u8_waves = num("AKO_HIP_U8_WAVES", 0);
-		t.tail_many = num("AKO_HIP_TAIL_MANY", 8);
-		if (t.tail_many < 8 || t.tail_many > TAIL_MAX)
-			t.tail_many = 8;
+		t.tail_many = num("AKO_HIP_TAIL_MANY", 4);
+		if (t.tail_many < 4 || t.tail_many > TAIL_MAX)
+			t.tail_many = 4;
 		t.floor_big = num("AKO_HIP_FLOOR_BIG", 24);
 		if (t.floor_big < 2)
 			t.floor_big = 2;
@@ -476,7 +476,7 @@ uint32_t tile_pack(const akoHipPlan* pl, const Group& g, const LevelGeom& L, boo
 {
 	if (!pl->tune.pack || u8 || pl->s.wrap == AKO_WRAP_REPEAT || g.tiles.size() < 2)
 		return 0;
-	if (L.tw < 8 || L.tw > 64 || (L.tw & (L.tw - 1)) != 0 || L.cw != 2 * L.tw || L.th < 2)
+	if (L.tw < 4 || L.tw > 64 || (L.tw & (L.tw - 1)) != 0 || L.cw != 2 * L.tw || L.th < 2)
 		return 0;
 	// the lanes address their tile instance and their tile's stream with 32-bit byte offsets from the image's first
 	if (pl->stream_values * 2 >= 0xFFF00000ull || (uint64_t)g.tiles.size() * pl->channels * scratch_plane_elems(g, 0) * 2 >= 0xFFF00000ull)

@@ -29,7 +29,7 @@ while time.time() < t_end:
             os.environ["AKO_HIP_SEG_ROWS"] = str(rng.choice([2, 6, 7, 12, 40]))
         os.environ["AKO_HIP_INV_PAIRS"] = str(rng.choice([1, 2, 4]))
         os.environ["AKO_HIP_FWD_PAIRS"] = str(rng.choice([1, 2, 4]))
-        os.environ["AKO_HIP_TAIL_MANY"] = str(rng.choice([8, 16, 32, 64]))
+        os.environ["AKO_HIP_TAIL_MANY"] = str(rng.choice([4, 8, 16, 32, 64]))
         os.environ["AKO_HIP_OPT"] = str(rng.integers(0, 2))
         os.environ["AKO_HIP_DEEP"] = str(rng.integers(0, 2))
         os.environ["AKO_KAGARI_THREADS"] = str(rng.choice([1, 4, 16]))
