@@ -57,7 +57,10 @@ def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
             # -fno-slp-vectorize: keeps hipcc from fusing scalar f32 adds into v_pk_add_f32, which costs
             # about two plain adds on gfx950 (MI355X_MICROARCH.md, cycle constants) and needs register pairs
             cmd = ([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                    "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"] + (extra_hip_flags or []) +
+                    "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+                    # keeps the unit's device assembly beside the object (build/<unit>-hip-amdgcn-amd-amdhsa-gfx950.s):
+                    # scripts/isa_lint.py and tests/test_isa_lint.py read the hot loops out of it
+                    "-save-temps=obj"] + (extra_hip_flags or []) +
                    os.environ.get("AKO_HIPCC_EXTRA", "").split() +  # experiments only
                    ["-c", os.path.join(CSRC, src), "-o", o])
             print(" ".join(cmd), flush=True)

@@ -142,6 +142,7 @@ struct Tuning
 	int lockstep = 3;      // AKO_HIP_LOCKSTEP: StreamGeom::lockstep (bit 0 barrier every six slots, bit 1 strip-major units)
 	int fwd_pairs = 2;     // AKO_HIP_FWD_PAIRS: pairs of waves (= neighbouring strips) per workgroup of the u8 forward kernel
 	int inv_pairs = 2;     // AKO_HIP_INV_PAIRS: same for the u8 inverse kernel (1, 2 or 4)
+	int interior = 1;      // AKO_HIP_LEAN=0: the general u8 level-0 kernels everywhere (not the lean ones of ako_u8_lean.hip.h)
 	int fuse2 = 0;         // AKO_HIP_FUSE2: levels 0 and 1 of eligible RGBA plans in one workgroup walk, the level-0 low-pass plane
 	                       // handed over through LDS (ako_fused.hip.h): bit 0 forward, bit 1 inverse.  Bit-exact and parity-tested,
 	                       // off by default: measured slower than the level-per-kernel launches
@@ -185,6 +186,7 @@ struct Tuning
 		t.lockstep = num("AKO_HIP_LOCKSTEP", 3) & 3;
 		t.fwd_pairs = num("AKO_HIP_FWD_PAIRS", 2);
 		t.inv_pairs = num("AKO_HIP_INV_PAIRS", 2);
+		t.interior = num("AKO_HIP_LEAN", 1) != 0;
 		if (t.fwd_pairs != 1 && t.fwd_pairs != 4)
 			t.fwd_pairs = 2;
 		if (t.inv_pairs != 1 && t.inv_pairs != 4)
@@ -714,12 +716,23 @@ void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, 
 		hipLaunchKernelGGL((k_inverse_stream<K_HAAR, NPL, U8, OPT, DEEP>), dim3(blocks), threads, 0, st, P, G);
 }
 
+// May this u8 level launch run on the lean kernels (ako_u8_lean.hip.h)?  They hold what carries practically all pixels --
+// YCoCg / YCoCg_Q without the discard rule, DD13/7 or CDF5/3, CLAMP / REPEAT / ZERO, a level width that is a multiple of
+// four (even number of coefficient columns, no phantom sample), ordinary strips -- and nothing else; MIRROR, Haar, other
+// colour modes, odd widths, wide strips and row strips over tiles stay on the general kernels.
+bool lean_u8_level(const akoHipPlan* pl, const LevelParams& P, const StreamGeom& G, int kind, bool forward)
+{
+	return pl->tune.interior && (kind == K_DD137 || kind == K_CDF53) && (P.color == C_YCOCG || P.color == C_YCOCG_Q) && !(forward && P.discard != 0) &&
+	       P.wrap != W_MIRROR && (P.full_w & 3u) == 0 && P.full_w == 2 * P.sub_w && G.wide == 0;
+}
+
 void launch_inverse_u8(const akoHipPlan* pl, bool opt, int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks)
 {
+	const bool lean = lean_u8_level(pl, P, G, kind, false);
 	if (pl->channels == 3)
-		akoLaunchInverseU8_rgb(kind, opt, P, G, blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
+		akoLaunchInverseU8_rgb(kind, opt, lean, P, G, blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 	else
-		akoLaunchInverseU8_rgba(kind, opt, P, G, blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
+		akoLaunchInverseU8_rgba(kind, opt, lean, P, G, blocks, (uint32_t)pl->tune.inv_pairs, pl->stream);
 }
 
 int check_blocks(uint64_t blocks)
@@ -1070,9 +1083,9 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				if (grouped)
 					akoLaunchForwardGroupU8_rgba(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else if (u8 && pl->channels == 3)
-					akoLaunchForwardU8_rgb(L.kind, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
+					akoLaunchForwardU8_rgb(L.kind, lean_u8_level(pl, P, G, L.kind, true), P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
 				else if (u8)
-					akoLaunchForwardU8_rgba(L.kind, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
+					akoLaunchForwardU8_rgba(L.kind, lean_u8_level(pl, P, G, L.kind, true), P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_forward_stream<1, false, DEEP_SLOTS_SHORT>(L.kind, narrow, P, G, (uint32_t)blocks, pl->stream);
 				else if (deep)
@@ -1338,7 +1351,7 @@ const char* akoHipLastError(void)
 uint64_t akoHipTuningSignature(void)
 {
 	const Tuning t = Tuning::from_env();
-	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.pack, t.row_strips, t.group, t.group_min, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, (int)t.dbg};
+	const int v[] = {t.path, t.tail, t.tail_max, t.wide, t.seg_rows, t.seg_rows_big, t.seg_rows_small, t.opt, t.staged, t.deep, t.u8_waves, t.lockstep, t.fwd_pairs, t.inv_pairs, t.fuse2, t.pack, t.row_strips, t.group, t.group_min, t.f2_rows, t.f2_edge, t.seg_rows_mid, t.seg_rows_mid_inv, t.floor_big, t.tail_many, t.interior, (int)t.dbg};
 	uint64_t h = 1469598103934665603ull;
 	for (int x : v)
 		h = (h ^ (uint64_t)(uint32_t)x) * 1099511628211ull;

@@ -1657,6 +1657,8 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		});
 		for (int base = 0; base < n_slots; base += 6)
 		{
+			if constexpr (U8 && KIND == K_DD137 && CH == 4 && CFAST && !GRP && !MEMONLY)  // (scripts/isa_lint.py finds the loop by this comment)
+				asm volatile("; AKO_LOOP fwd_u8_general_h%0_v%1" ::"n"((int)HEDGE), "n"((int)VEDGE));
 			if (!GRP && (G.lockstep & 1))  // (column groups meet at every row slot)
 				__builtin_amdgcn_s_barrier();
 			static_for<6>([&](auto kc) {
@@ -2327,6 +2329,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 			fetch(v_begin + 1, ring[1]);
 		for (int base = 0; base < n_slots; base += 6)
 		{
+			if constexpr (U8 && OPT && KIND == K_DD137 && CH == 4 && !MEMONLY)  // (scripts/isa_lint.py finds the loop by this comment)
+				asm volatile("; AKO_LOOP inv_u8_general_h%0_v%1" ::"n"((int)HEDGE), "n"((int)VEDGE));
 			if constexpr (!U8)  // (the u8 pairs already meet at the barriers of their LDS exchange, every slot)
 			{
 				if (G.lockstep & 1)
@@ -2439,3 +2443,5 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(AKO_U8_WAVE
 #endif  // AKO_MEASURE
 
 }  // namespace ako
+
+#include "ako_u8_lean.hip.h"  // the lean u8 level-0 kernels (round 4)

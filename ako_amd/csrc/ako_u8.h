@@ -6,12 +6,13 @@
 namespace ako
 {
 
-void akoLaunchForwardU8_rgba(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
-void akoLaunchForwardU8_rgb(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
+void akoLaunchForwardU8_rgba(int kind, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
+void akoLaunchForwardU8_rgb(int kind, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
 // level 0 in column groups (k_forward_group_u8; ako_u8_group.hip): workgroups of 8 waves, G.strips = number of groups
 void akoLaunchForwardGroupU8_rgba(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, hipStream_t st);
+// lean: the lean kernels of ako_u8_lean.hip.h (the caller has checked lean_u8_level(): colour, border rule, width, strips)
 // opt: the optimistic fp32 pipeline (false: the exact int16-wrapping kernel, which returns at once unless flagged)
-void akoLaunchInverseU8_rgba(int kind, bool opt, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
-void akoLaunchInverseU8_rgb(int kind, bool opt, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
+void akoLaunchInverseU8_rgba(int kind, bool opt, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
+void akoLaunchInverseU8_rgb(int kind, bool opt, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
 
 }  // namespace ako

@@ -1,0 +1,687 @@
+// ako_u8_lean.hip.h -- the LEAN u8 level-0 kernels (round 4): k_forward_u8_lean / k_inverse_u8_lean.
+//
+// Same strip walk, same arithmetic and same results as k_forward_stream_u8 / k_inverse_stream_u8 (ako_stream.hip.h: one
+// wave64 per strip of 128 coefficient columns and pair of planes, rows in registers, taps through DPP shifts, column pass
+// as a register pipeline), for the configurations that carry practically all pixels: YCoCg / YCoCg_Q colour, DD13/7 or
+// CDF5/3, CLAMP / REPEAT / ZERO borders, level widths that are multiples of four, ordinary strips (no wide strip, no
+// row strips over tiles).  Everything else -- MIRROR, Haar, other colour modes, the discard rule, odd widths, packed
+// tiles -- stays on the general kernels, which the host picks per launch (ako_plan.hip: lean_u8_level()).
+//
+// Why a second pair of kernels (measured on one box in one call, profiles/r4_lean_ab.txt):
+//   * NO SCRATCH.  The general kernels serve every geometry from one source; their border bodies spill (76 / 104 bytes of
+//     private segment in round 3).  A private segment costs a launch time even when no wave ever touches it: the lean
+//     inverse kernel alone 0.209 ms, the same kernel with 176 unused bytes of scratch 0.230 ms, with the general border
+//     bodies linked in 0.250 ms.  Every body here fits its 128 registers without a spill, so the kernels have no private
+//     segment at all (tests/test_isa_lint.py checks the kernel descriptors)
+//   * NO CONTROL FLOW in the row loops.  ROLE (which wave of the pair), left / right border and top / bottom border are
+//     template parameters; what is left of the border rules are selects on wave-uniform or per-lane masks
+//     (fix_halo_lanes_bf, vstep_*_bf).  The general border bodies branch around every patch: a strip at a tile border ran
+//     2.4-3 x the instructions of an interior one (6 000-7 900 against 2 500 per six slots, with up to 200 scratch accesses)
+//     and its waves were the tail of the launch
+//   * the first trip of six row slots only fills the column pipeline (its output rows belong to the segment above): it
+//     runs without row pass / swap / colour / stores (inverse) and without gate, quantizer and stores (forward)
+//   * inverse: the plane swap goes through LDS as [plane][sample][lane] dwords (no four-register staging for 16-byte LDS
+//     accesses: 288 moves per six slots in round 3), de-quantization is an unconditional multiply, and ONE proof obligation
+//     covers the optimistic fp32 pipeline: |input| <= OPT_INPUT_BOUND_TIGHT bounds every lifted sample by 9.2 x that
+//     <= OPT_OUTPUT_BOUND, so the outputs need not be tracked (the exact kernel behind it is the general one, as before)
+// VALU instructions per six row slots of an interior wave: inverse 2 166 -> 1 790, forward 2 162 -> see profiles/r4_isa_lint.txt.
+//
+// Reference: library/wavelet-dd137.c:57-702, wavelet-cdf53.c:57-362, format.c:87-229, lifting.c:30-40,154-168.
+#pragma once
+
+namespace ako
+{
+
+#ifndef AKO_U8L_INV_PF
+#define AKO_U8L_INV_PF 1  // row slots the lean inverse kernel fetches ahead (1 or 2; 2 measured no faster)
+#endif
+
+// |input| <= 1187  =>  |lifted sample| <= 9.2 * 1187 < 10921 = OPT_OUTPUT_BOUND  (see OPT_INPUT_BOUND in ako_stream.hip.h)
+constexpr float OPT_INPUT_BOUND_TIGHT = 1187.0f;
+
+// LDS of one pair of waves for the plane swap: [slot parity][destination role][plane][sample][lane] floats = 8 KiB
+constexpr int XI_PLANE = 4 * 64, XI_ROLE = 2 * XI_PLANE, XI_BUF = 2 * XI_ROLE;
+static_assert(2 * XI_BUF * sizeof(float) == INV_U8_LDS_PER_PAIR, "same LDS per pair as the general kernel");
+
+// ---- left / right tile border without control flow (CLAMP and ZERO) -----------------------------------------------
+// fix_halo_lanes() (ako_stream.hip.h) asks per side whether the strip has lanes beyond the border and branches around the
+// patch; with eight row lifts per slot that cut the slot into a hundred basic blocks.  Here both sides are patched
+// unconditionally: two v_readlane + four v_cndmask per sequence, with lane masks that are simply empty on a side without
+// such lanes.  CLAMP takes the nearest in-range value, ZERO zero (wavelet-dd137.c:76-79,110-125); REPEAT strips never have
+// such lanes (they wrap their load addresses, lane_columns()) and run the bodies without border code.
+struct HEdgeBF
+{
+	bool oob_l, oob_r;          // this lane lies beyond the left / right border
+	int lane_first, lane_last;  // the lanes that hold columns 0,1 / T-2,T-1 (any valid lane on a side without border)
+	bool zero;                  // W_ZERO
+};
+__device__ __forceinline__ HEdgeBF hedge_bf(const HEdge& he)
+{
+	HEdgeBF e;
+	e.oob_l = he.left && he.oob_l, e.oob_r = he.right && he.oob_r;
+	e.lane_first = he.lane_first & 63, e.lane_last = min(max(he.lane_last, 0), 63);
+	e.zero = he.wrap == W_ZERO;
+	return e;
+}
+template <typename V>
+__device__ __forceinline__ void fix_halo_lanes_bf(V& a0, V& a1, const HEdgeBF& e)
+{
+	V fl = read_lane(a0, e.lane_first), fr = read_lane(a1, e.lane_last);
+	if (e.zero)  // wave-uniform: scalar selects
+		fl = (V)0, fr = (V)0;
+	a0 = e.oob_l ? fl : a0, a1 = e.oob_l ? fl : a1;
+	a0 = e.oob_r ? fr : a0, a1 = e.oob_r ? fr : a1;
+}
+// A neighbour tap that feeds TWO sums: kept as one DPP move whose result the compiler may not fold away again.  Left alone it
+// folds the tap into one of its consumers (a DPP add issues at the rate of a DPP move, half that of a plain add) and still
+// needs the move for the other.
+template <typename V>
+__device__ __forceinline__ V keep_tap(V x)
+{
+	asm("" : "+v"(x));
+	return x;
+}
+// hlift_inverse() / hlift_forward() of ako_stream.hip.h with that border patch (HB = false: none at all)
+template <int KIND, bool HB, typename V>
+__device__ __forceinline__ void hlift_inverse_bf(V L0, V L1, V H0, V H1, const HEdgeBF& e, V& E0, V& O0, V& E1, V& O1)
+{
+	static_assert(KIND != K_HAAR, "lifting wavelets");
+	if constexpr (HB)
+		fix_halo_lanes_bf(H0, H1, e);
+	const V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
+	V hL0 = (V)0, hR0 = (V)0;
+	if constexpr (KIND == K_DD137)
+		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	E0 = lift_add<false>(L0, sum_u<KIND, -1>(hL0, hL1, H0, H1), shift_u<KIND>());
+	E1 = lift_add<false>(L1, sum_u<KIND, -1>(hL1, H0, H1, hR0), shift_u<KIND>());
+	if constexpr (HB)
+		fix_halo_lanes_bf(E0, E1, e);
+	const V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
+	V eL = (V)0, eR1 = (V)0;
+	if constexpr (KIND == K_DD137)
+		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	O0 = lift_add<false>(H0, sum_p<KIND, -1>(eL, E0, E1, eR0), shift_p<KIND>());
+	O1 = lift_add<false>(H1, sum_p<KIND, -1>(E0, E1, eR0, eR1), shift_p<KIND>());
+}
+template <int KIND, bool HB, typename V>
+__device__ __forceinline__ void hlift_forward_bf(V E0, V O0, V E1, V O1, const HEdgeBF& e, V& L0, V& L1, V& H0, V& H1)
+{
+	static_assert(KIND != K_HAAR, "lifting wavelets");
+	if constexpr (HB)
+		fix_halo_lanes_bf(E0, E1, e);
+	const V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
+	V eL = (V)0, eR1 = (V)0;
+	if constexpr (KIND == K_DD137)
+		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	H0 = lift_add<false>(O0, sum_p<KIND, +1>(eL, E0, E1, eR0), shift_p<KIND>());
+	H1 = lift_add<false>(O1, sum_p<KIND, +1>(E0, E1, eR0, eR1), shift_p<KIND>());
+	if constexpr (HB)
+		fix_halo_lanes_bf(H0, H1, e);
+	const V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
+	V hL0 = (V)0, hR0 = (V)0;
+	if constexpr (KIND == K_DD137)
+		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	L0 = lift_add<false>(E0, sum_u<KIND, +1>(hL0, hL1, H0, H1), shift_u<KIND>());
+	L1 = lift_add<false>(E1, sum_u<KIND, +1>(hL1, H0, H1, hR0), shift_u<KIND>());
+}
+
+// ---- top / bottom tile border without control flow (CLAMP, REPEAT, ZERO) -------------------------------------------
+// vstep_forward() / vstep_inverse() of ako_stream.hip.h with the border patches as selects on wave-uniform conditions
+// (the row slot v is a scalar): REPEAT patches nothing (its rows come in through map_index), CLAMP repeats the nearest
+// row of the produced sequence, ZERO zeroes it.
+struct VEdgeBF
+{
+	bool patch;  // CLAMP or ZERO
+	bool zero;   // ZERO
+};
+// map_index() (ako_kernels.hip.h) as scalar selects: the row a slot v in [-3, T + 2] reads.  CLAMP: the nearest row; REPEAT: v mod T
+// (two conditional steps each way, as there); ZERO: any valid row (the callers zero what they read).  Further out -- the slots
+// a trip of six runs past the segment, the prefetch -- any valid row will do.
+__device__ __forceinline__ int map_index_bf(int v, int T, int wrap)
+{
+	const int t = (wrap == W_REPEAT) ? T : 0;
+	int m = v;
+	m += (m < 0) ? t : 0;
+	m += (m < 0) ? t : 0;
+	m -= (m >= T) ? t : 0;
+	m -= (m >= T) ? t : 0;
+	return min(max(m, 0), T - 1);
+}
+template <int KIND, bool VEDGE, int K>
+__device__ __forceinline__ void vstep_forward_bf(VFwd<float>& s, float E, float O, int v, const VEdgeBF& ve, int T, float& lp_out,
+                                                 float& hp_out)
+{
+	float& eA = s.e[K % 3];        // E[v-3]   (overwritten by E[v] at the end)
+	float& eB = s.e[(K + 1) % 3];  // E[v-2]
+	float& eC = s.e[(K + 2) % 3];  // E[v-1]
+	float& oA = s.o[K % 2];        // O[v-2]   (overwritten by O[v])
+	float& hA = s.h[K % 3];        // HP[v-5]  (overwritten by HP[v-2])
+	float& hB = s.h[(K + 1) % 3];  // HP[v-4]
+	float& hC = s.h[(K + 2) % 3];  // HP[v-3]
+	float H = lift_add<false>(oA, sum_p<KIND, +1>(eA, eB, eC, E), shift_p<KIND>());
+	if constexpr (VEDGE)
+	{
+		const int u = v - 2;
+		const bool beyond = ve.patch && (u >= T), before = ve.zero && (u < 0), first = ve.patch && !ve.zero && (u == 0);
+		const float edge = ve.zero ? 0.0f : hC;  // HP[T] := HP[T-1]
+		H = beyond ? edge : H;
+		H = before ? 0.0f : H;
+		hB = first ? H : hB, hC = first ? H : hC;  // HP[-2] = HP[-1] := HP[0]
+	}
+	lp_out = lift_add<false>(eA, sum_u<KIND, +1>(hA, hB, hC, H), shift_u<KIND>());
+	hp_out = hC;
+	eA = E, oA = O, hA = H;
+}
+template <int KIND, bool VEDGE, int K>
+__device__ __forceinline__ void vstep_inverse_bf(VInv<float>& s, float LP, float HP, int v, const VEdgeBF& ve, int T, float& even_out,
+                                                 float& odd_out)
+{
+	float& hA = s.h[K % 3];        // HP[v-3]  (overwritten by HP[v])
+	float& hB = s.h[(K + 1) % 3];  // HP[v-2]
+	float& hC = s.h[(K + 2) % 3];  // HP[v-1]
+	float& eA = s.e[K % 3];        // E[v-4]   (overwritten by E[v-1])
+	float& eB = s.e[(K + 1) % 3];  // E[v-3]
+	float& eC = s.e[(K + 2) % 3];  // E[v-2]
+	float Ev = lift_add<false>(s.l, sum_u<KIND, -1>(hA, hB, hC, HP), shift_u<KIND>());
+	if constexpr (VEDGE)
+	{
+		const int re = v - 1, ro = v - 3;
+		const bool beyond = ve.patch && (re >= T), before = ve.zero && (re < 0), first = ve.patch && (ro == 0);
+		const float edge = ve.zero ? 0.0f : eC;  // E[T] := E[T-1]
+		Ev = beyond ? edge : Ev;
+		Ev = before ? 0.0f : Ev;
+		const float lead = ve.zero ? 0.0f : eB;  // E[-1] := E[0]
+		eA = first ? lead : eA;
+	}
+	even_out = eB;
+	odd_out = lift_add<false>(hA, sum_p<KIND, -1>(eA, eB, eC, Ev), shift_p<KIND>());
+	hA = HP, s.l = LP, eA = Ev;
+}
+
+// =====================================================================================================================
+// Inverse.  Role 0 carries planes 0, 1 (Y, Co) and finishes the even pixel row of a slot, role 1 planes 2, 3 (Cg, alpha;
+// RGB: Cg alone) and the odd row; the rows' other planes cross through LDS (one barrier per slot, double buffered).
+// =====================================================================================================================
+template <int KIND, int CH, int ROLE, bool HEDGE, bool VEDGE>
+__device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const StreamGeom& G, const UnitId& id, const LaneCols& lc, int lane,
+                                                float* xb)
+{
+	static_assert(CH == 4 || CH == 3, "RGBA or RGB");
+	constexpr int NP = (CH == 3 && ROLE == 1) ? 1 : 2;      // planes this wave carries
+	constexpr int NP_HIS = (CH == 3 && ROLE == 0) ? 1 : 2;  // planes the partner sends
+	constexpr uint32_t OOB = 0xFFFFFFFFu;
+	constexpr int RSRC_FLAGS = 0x00020000;
+
+	const TileDesc td = P.tiles[id.tile];
+	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
+	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
+	const int oh = (int)P.full_h;
+	const int wrap = P.wrap;
+	int r_lo, r_hi, seg_len;
+	segment_rows(G, id.seg, Tr, r_lo, r_hi, seg_len);
+	(void)seg_len;
+
+	const int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(tile_stream), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
+	const int16_t* ll_root = P.ll_in_stream ? tile_stream : (P.src + inst * P.src_inst_stride);
+	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(ll_root), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
+	const uint32_t ll_pitch_b = (P.ll_in_stream ? (uint32_t)Tc : P.src_pitch) * 2u;
+	const uint32_t sub_pitch_b = (uint32_t)Tc * 2u;
+	const uint32_t nsub_b = (uint32_t)((uint64_t)Tc * Tr * 2);
+	// (lanes beyond a tile border read their clamped / wrapped pair, lane_columns(); HEDGE patches them for every rule but REPEAT)
+	const uint32_t lane_in_off = (uint32_t)lc.cs * 2u;
+
+	uint32_t ll_off[NP], grp_off[NP];
+	float qf[NP];
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+	{
+		const int pl = 2 * ROLE + p;
+		// the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116); one tile per wave: wave-uniform
+		const int q = __builtin_amdgcn_readfirstlane((int)tile_stream[P.grp_off[pl]]);
+		qf[p] = (q > 1) ? (float)q : 1.0f;  // lifting.c:30-40: multiply only when q > 1
+		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1) * 2);
+		ll_off[p] = (uint32_t)((P.ll_in_stream ? P.lp_off[pl] : (uint64_t)pl * P.src_plane_stride) * 2);
+	}
+
+	uint8_t* img = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * CH;
+	const uint32_t out_pitch_b = P.img_pitch * (uint32_t)CH;
+	const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
+	const bool store_lane = lc.net && (lc.c0 >= 0) && (lc.c0 < Tc);
+	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * lc.c0) * (uint32_t)CH : OOB;
+	const float ysc = (P.color == C_YCOCG_Q) ? 0.5f : 1.0f;  // format.c:170: y = in / 2 first
+
+	VInv<float> st[NP][4];
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			st[p][k] = VInv<float>{{0, 0, 0}, {0, 0, 0}, 0};
+	float peak_in = 0.0f;
+	const HEdgeBF he = hedge_bf(lc.he);
+	const VEdgeBF ve = {wrap != W_REPEAT, wrap == W_ZERO};
+
+	struct Raw
+	{
+		uint32_t ll[NP], c[NP], b[NP], d[NP];
+	};
+	auto fetch = [&](int v, Raw& raw) {
+		const int m = VEDGE ? map_index_bf(v, Tr, wrap) : v;  // (ZERO's rows beyond the border: any row, zeroed in column_pass)
+		const uint32_t row_g = (uint32_t)m * sub_pitch_b, row_l = (uint32_t)m * ll_pitch_b;
+#pragma unroll
+		for (int p = 0; p < NP; p++)
+		{
+			const uint32_t g = grp_off[p] + row_g;
+			raw.ll[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_ll, lane_in_off, ll_off[p] + row_l, 0);
+			raw.c[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g, AUX_INV_STREAM_LOAD);
+			raw.b[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + nsub_b, AUX_INV_STREAM_LOAD);
+			raw.d[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + 2u * nsub_b, AUX_INV_STREAM_LOAD);
+		}
+	};
+
+	// unpack + de-quantize + column pass of one slot: even / odd sample rows of slot v - 3 as [plane][row low-pass c0 c1, row high-pass c0 c1]
+	auto column_pass = [&](auto kc, const int v, const Raw& raw, float (&ev)[NP][4], float (&od)[NP][4]) {
+		constexpr int K = decltype(kc)::value;
+		const bool zero_row = VEDGE && ve.zero && ((unsigned)v >= (unsigned)Tr);  // wave-uniform
+#pragma unroll
+		for (int p = 0; p < NP; p++)
+		{
+			float lpv[4], hpv[4];  // columns: 0,1 = row low-pass (LL over C); 2,3 = row high-pass (B over D)
+			unpack2_f(raw.ll[p], lpv[0], lpv[1]);
+			unpack2_f(raw.b[p], lpv[2], lpv[3]);
+			unpack2_f(raw.c[p], hpv[0], hpv[1]);
+			unpack2_f(raw.d[p], hpv[2], hpv[3]);
+			lpv[2] *= qf[p], lpv[3] *= qf[p];
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				hpv[k] *= qf[p];
+#pragma unroll
+			for (int k = 0; k < 4; k += 2)
+			{
+				absmax3(peak_in, lpv[k], lpv[k + 1]);
+				absmax3(peak_in, hpv[k], hpv[k + 1]);
+			}
+			if constexpr (VEDGE)
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					lpv[k] = zero_row ? 0.0f : lpv[k], hpv[k] = zero_row ? 0.0f : hpv[k];
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				vstep_inverse_bf<KIND, VEDGE, K>(st[p][k], lpv[k], hpv[k], v, ve, Tr, ev[p][k], od[p][k]);
+		}
+	};
+
+	float* const xw = xb + (1 - ROLE) * XI_ROLE + lane;  // what this wave sends: the partner's row
+	const float* const xr = xb + ROLE * XI_ROLE + lane;  // what it receives: the partner's planes of its own row
+	auto full_slot = [&](auto kc, const int v, const Raw& raw) {
+		constexpr int K = decltype(kc)::value;
+		float ev[NP][4], od[NP][4];
+		column_pass(kc, v, raw, ev, od);
+		// row pass: this wave finishes pixel row ROLE of the slot (role 0 the even one), the other row's planes go to the partner
+		float mine[NP][4], send[NP][4];
+#pragma unroll
+		for (int p = 0; p < NP; p++)
+		{
+			float (&me)[4] = mine[p];
+			float (&sd)[4] = send[p];
+			if constexpr (ROLE == 0)
+			{
+				hlift_inverse_bf<KIND, HEDGE, float>(ev[p][0], ev[p][1], ev[p][2], ev[p][3], he, me[0], me[1], me[2], me[3]);
+				hlift_inverse_bf<KIND, HEDGE, float>(od[p][0], od[p][1], od[p][2], od[p][3], he, sd[0], sd[1], sd[2], sd[3]);
+			}
+			else
+			{
+				hlift_inverse_bf<KIND, HEDGE, float>(ev[p][0], ev[p][1], ev[p][2], ev[p][3], he, sd[0], sd[1], sd[2], sd[3]);
+				hlift_inverse_bf<KIND, HEDGE, float>(od[p][0], od[p][1], od[p][2], od[p][3], he, me[0], me[1], me[2], me[3]);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				xw[(K & 1) * XI_BUF + p * XI_PLANE + k * 64] = sd[k];
+		}
+		__syncthreads();  // (one barrier per slot, double buffered: see inverse_stream_body)
+		float his[2][4] = {};
+#pragma unroll
+		for (int p = 0; p < NP_HIS; p++)
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				his[p][k] = xr[(K & 1) * XI_BUF + p * XI_PLANE + k * 64];
+
+		const int r = v - 3, y = 2 * r + ROLE;
+		const bool row_ok = (r >= r_lo) && (r < r_hi) && (y < oh);  // wave-uniform; phantom last row dropped (lifting.c:112,141)
+		uint32_t px[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			// format.c:138-191: t = y - v / 2; g = v + t; b = t - u / 2; r = b + u  (planes: y, u = Co, v = Cg)
+			float yy, co, cg, al = 0.0f;
+			if constexpr (ROLE == 0)
+			{
+				yy = mine[0][k], co = mine[1][k], cg = his[0][k];
+				if constexpr (CH == 4)
+					al = his[1][k];
+			}
+			else
+			{
+				yy = his[0][k], co = his[1][k], cg = mine[0][k];
+				if constexpr (CH == 4)
+					al = mine[1][k];
+			}
+			const float t = __builtin_truncf(yy * ysc) - half_trunc(cg);
+			const float gg = cg + t;
+			const float bb = t - half_trunc(co);
+			const float rr = bb + co;
+			px[k] = pixel_u8x4(rr, gg, bb, al);
+		}
+		const uint32_t s_row = row_ok ? (uint32_t)y * out_pitch_b : OOB;
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		if constexpr (CH == 3)
+			__builtin_amdgcn_raw_buffer_store_b96(rgb_pack4(px), rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
+		else
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{px[0], px[1], px[2], px[3]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
+		AKO_STORE_GUARD();  // (see store_b128_guarded)
+	};
+
+	// slots v_begin .. r_hi + 2; slot v consumes quadrant row v and finishes sample rows 2 (v - 3), 2 (v - 3) + 1.  The first six
+	// slots finish rows r_lo - 6 .. r_lo - 1, which belong to the segment above (or do not exist): they only fill the pipeline.
+	const int v_begin = r_lo - 3;
+	const int n_slots = r_hi + 3 - v_begin;
+	// PF row slots are fetched ahead of the one being worked on (the rows exist: segment_needs_border_code() keeps twelve
+	// rows between a body without row border code and the bottom border; VEDGE maps every row into the tile)
+	constexpr int PF = AKO_U8L_INV_PF;
+	static_assert(PF == 1 || PF == 2, "the ring index must repeat with the unrolled row loop");
+	Raw ring[PF + 1];
+	static_for<PF>([&](auto jc) { fetch(v_begin + decltype(jc)::value, ring[decltype(jc)::value]); });
+	static_for<6>([&](auto kc) {
+		constexpr int K = decltype(kc)::value;
+		const int v = v_begin + K;
+		fetch(v + PF, ring[(K + PF) % (PF + 1)]);
+		__builtin_amdgcn_sched_barrier(0);  // (the compiler would sink the loads to where their registers are free: half the prefetch distance)
+		float ev[NP][4], od[NP][4];
+		column_pass(kc, v, ring[K % (PF + 1)], ev, od);
+		(void)ev, (void)od;
+		__builtin_amdgcn_sched_barrier(0);
+		// as many (dropped) stores behind the loads as a full slot issues: the memory operations in flight then look the same on
+		// entry to the loop below as on every later trip, and the wait in front of a slot's coefficients stays a counted one
+		if constexpr (K == 5)
+			__builtin_amdgcn_raw_buffer_store_b32(0u, rs_img, OOB, 0, 0);
+	});
+	for (int base = 6; base < n_slots; base += 6)
+	{
+		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
+			asm volatile("; AKO_LOOP inv_u8_lean_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+		static_for<6>([&](auto kc) {
+			constexpr int K = decltype(kc)::value;
+			const int v = v_begin + base + K;
+			fetch(v + PF, ring[(K + PF) % (PF + 1)]);
+			__builtin_amdgcn_sched_barrier(0);
+			full_slot(kc, v, ring[K % (PF + 1)]);
+		});
+	}
+	const bool bad = !(peak_in <= OPT_INPUT_BOUND_TIGHT);  // negated: NaN counts as bad
+	if (__any(bad) && lane == 0)
+		atomicMax(P.ovf_flag, P.ovf_gen);
+}
+
+// the workgroup is 1, 2 or 4 pairs of waves (neighbouring strips); 8 KiB of dynamic LDS per pair, as k_inverse_stream_u8
+template <int KIND, int CH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inverse_u8_lean(const LevelParams P, const StreamGeom G)
+{
+	extern __shared__ float xlean[];
+	float* xb = xlean + (threadIdx.x >> 7) * (2 * XI_BUF);
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;  // units come in pairs, so both waves of a pair leave together (a barrier does not wait for ended waves)
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	// (strip and segment are the pair's: both its waves take the same way, and execute the same sequence of barriers)
+#define AKO_INV_LEAN(H, V)                                                       \
+	do                                                                           \
+	{                                                                            \
+		if (id.pg == 0)                                                          \
+			inverse_u8_lean<KIND, CH, 0, H, V>(P, G, id, lc, lane, xb);          \
+		else                                                                     \
+			inverse_u8_lean<KIND, CH, 1, H, V>(P, G, id, lc, lane, xb);          \
+	} while (0)
+	if (__builtin_expect(vedge, 0))
+	{
+		if (lc.hedge)
+			AKO_INV_LEAN(true, true);
+		else
+			AKO_INV_LEAN(false, true);
+	}
+	else
+	{
+		if (lc.hedge)
+			AKO_INV_LEAN(true, false);
+		else
+			AKO_INV_LEAN(false, false);
+	}
+#undef AKO_INV_LEAN
+}
+
+// =====================================================================================================================
+// Forward.  Role 0 carries planes 0, 2 (Y, Cg: they share t = b + Co / 2), role 1 planes 1, 3 (Co, alpha; RGB: Co alone);
+// both waves of a pair load the same pixels.
+// =====================================================================================================================
+template <int KIND, int CH, int ROLE, bool HEDGE, bool VEDGE>
+__device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const StreamGeom& G, const UnitId& id, const LaneCols& lc, int lane)
+{
+	static_assert(CH == 4 || CH == 3, "RGBA or RGB");
+	constexpr int NP = (CH == 3 && ROLE == 1) ? 1 : 2;
+	constexpr uint32_t OOB = 0xFFFFFFFFu;
+	constexpr int RSRC_FLAGS = 0x00020000;
+
+	const TileDesc td = P.tiles[id.tile];
+	const uint64_t inst = (uint64_t)id.image * P.n_tiles + id.tile;
+	const int Tc = (int)P.sub_w, Tr = (int)P.sub_h;
+	const int chh = (int)P.full_h;
+	const int wrap = P.wrap;
+	int r_lo, r_hi, seg_len;
+	segment_rows(G, id.seg, Tr, r_lo, r_hi, seg_len);
+	(void)seg_len;
+
+	// source: the tile's pixels through a raw buffer resource, the lane's four pixels ONE register of byte offset
+	const uint8_t* src_base = P.img + (uint64_t)id.image * P.img_stride + ((uint64_t)td.y0 * P.img_pitch + td.x0) * CH;
+	const uint32_t row_pitch_b = P.img_pitch * (uint32_t)CH;
+	const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_base), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
+	const uint32_t src_lane_off = (uint32_t)lc.xs * (uint32_t)CH;
+
+	// destinations (see forward_stream_body: out-of-range offsets drop the stores of lanes / rows that must not store)
+	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+	const uint64_t stream_left = (P.stream_stride - td.stream_off) * 2;  // bytes up to the end of the image's stream
+	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(
+	    tile_stream, 0, (int)(uint32_t)(stream_left < 0xFFFFFFFFull ? stream_left : 0xFFFFFFFFull), RSRC_FLAGS);
+	int16_t* ll_root = P.ll_out_stream ? tile_stream : (P.dst + inst * P.dst_inst_stride);
+	const uint64_t ll_left = P.ll_out_stream ? stream_left : (uint64_t)P.channels * P.dst_plane_stride * 2;
+	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(
+	    ll_root, 0, (int)(uint32_t)(ll_left < 0xFFFFFFFFull ? ll_left : 0xFFFFFFFFull), RSRC_FLAGS);
+	const uint32_t ll_pitch_b = (P.ll_out_stream ? (uint32_t)Tc : P.dst_pitch) * 2u;
+	const uint32_t sub_pitch_b = (uint32_t)Tc * 2u;
+	const uint32_t nsub_b = (uint32_t)((uint64_t)Tc * Tr * 2);
+	const bool store_lane = lc.net && (lc.c0 >= 0) && (lc.c0 < Tc);
+	const uint32_t lane_off = store_lane ? (uint32_t)(lc.c0 * 2) : OOB;
+	uint32_t ll_off[NP], grp_off[NP];
+	float gf[NP], rq[NP];
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+	{
+		const int pl = ROLE + 2 * p;
+		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1) * 2);
+		ll_off[p] = (uint32_t)((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) * 2);
+		gf[p] = (float)((pl == 0) ? P.g_luma : P.g_chroma);  // lifting.c:202-211: every plane but the first is "chroma"
+		rq[p] = (pl == 0) ? P.rq_luma : P.rq_chroma;
+		if (id.strip == 0 && id.seg == 0 && lane == 0)  // the lift head (lifting.c:266-267)
+			tile_stream[P.grp_off[pl]] = (int16_t)((pl == 0) ? P.q_luma : P.q_chroma);
+	}
+	const float ymul = (P.color == C_YCOCG_Q) ? 2.0f : 1.0f;
+
+	VFwd<float> st[NP][4];
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			st[p][k] = VFwd<float>{{0, 0, 0}, {0, 0}, {0, 0, 0}};
+	const HEdgeBF he = hedge_bf(lc.he);
+	const VEdgeBF ve = {wrap != W_REPEAT, wrap == W_ZERO};
+
+	struct Raw
+	{
+		uint4 a[2];  // the two pixel rows of a slot
+	};
+	auto fetch = [&](int v, Raw& raw) {
+		const int m = VEDGE ? map_index_bf(v, Tr, wrap) : v;
+#pragma unroll
+		for (int par = 0; par < 2; par++)
+		{
+			const int y = VEDGE ? min(2 * m + par, chh - 1) : (2 * m + par);  // phantom last row = copy of the last row
+			const uint32_t row_off = (uint32_t)y * row_pitch_b;
+			if constexpr (CH == 3)
+			{
+				typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+				const u32x3 t = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(rs_src, src_lane_off, row_off, AUX_FWD_PIXEL_LOAD));
+				raw.a[par] = uint4{t.x, t.y, t.z, 0u};
+			}
+			else
+				raw.a[par] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, src_lane_off, row_off, AUX_FWD_PIXEL_LOAD));
+		}
+	};
+
+	// pixels -> samples -> row pass -> column pass of one slot: low-pass / high-pass rows of slot v - 3, [plane][row LP c0 c1, row HP c0 c1]
+	auto lift_slot = [&](auto kc, const int v, Raw& raw, float (&lp)[NP][4], float (&hp)[NP][4]) {
+		constexpr int K = decltype(kc)::value;
+		const bool zero_row = VEDGE && ve.zero && ((unsigned)v >= (unsigned)Tr);
+		float smp[2][2][4];
+#pragma unroll
+		for (int par = 0; par < 2; par++)
+		{
+			uint32_t px[4] = {raw.a[par].x, raw.a[par].y, raw.a[par].z, raw.a[par].w};
+			if constexpr (CH == 3)
+			{
+				// twelve bytes = four RGB pixels: each into the low three bytes of a dword
+				px[3] = raw.a[par].z >> 8;
+				px[2] = __builtin_amdgcn_alignbit(raw.a[par].z, raw.a[par].y, 16);
+				px[1] = __builtin_amdgcn_alignbit(raw.a[par].y, raw.a[par].x, 24);
+			}
+			decode_pixels_ycocg<float>(px, ymul, ROLE, smp[par][0], smp[par][1]);
+			if constexpr (VEDGE)
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					smp[par][0][k] = zero_row ? 0.0f : smp[par][0][k], smp[par][1][k] = zero_row ? 0.0f : smp[par][1][k];
+		}
+		// the slot's pixels are samples now: the next slot's go into the registers they left
+		__builtin_amdgcn_sched_barrier(0);
+		fetch(v + 1, raw);
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int p = 0; p < NP; p++)
+		{
+			float e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
+			hlift_forward_bf<KIND, HEDGE, float>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], he, e[0], e[1], e[2], e[3]);
+			hlift_forward_bf<KIND, HEDGE, float>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], he, o[0], o[1], o[2], o[3]);
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[k], o[k], v, ve, Tr, lp[p][k], hp[p][k]);
+		}
+	};
+	auto full_slot = [&](auto kc, const int v, Raw& raw) {
+		float lp[NP][4], hp[NP][4];
+		lift_slot(kc, v, raw, lp, hp);
+		const int r = v - 3;
+		const bool row_ok = (r >= r_lo) && (r < r_hi);  // wave-uniform
+		const uint32_t row_grp = (uint32_t)r * sub_pitch_b, row_ll = (uint32_t)r * ll_pitch_b;
+#pragma unroll
+		for (int p = 0; p < NP; p++)
+		{
+			// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP); gate + quantizer: lifting.c:154-168
+			uint32_t w_ll, w_c, w_b, w_d;
+			pack_row_f(lp[p], hp[p], gf[p], rq[p], w_ll, w_c, w_b, w_d);
+			const uint32_t s_ll = row_ok ? ll_off[p] + row_ll : OOB;
+			const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
+			const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
+			const uint32_t s_d = row_ok ? grp_off[p] + row_grp + 2u * nsub_b : OOB;
+			__builtin_amdgcn_raw_buffer_store_b32(w_ll, rs_ll, lane_off, s_ll, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(w_c, rs_stream, lane_off, s_c, AUX_FWD_STREAM_STORE);
+			__builtin_amdgcn_raw_buffer_store_b32(w_b, rs_stream, lane_off, s_b, AUX_FWD_STREAM_STORE);
+			__builtin_amdgcn_raw_buffer_store_b32(w_d, rs_stream, lane_off, s_d, AUX_FWD_STREAM_STORE);
+		}
+	};
+	// (dropped) stores: as many as a full slot issues, so that the memory operations in flight look the same on entry to the
+	// main loop as on every later trip (stores count in vmcnt on gfx950)
+	auto phantom_stores = [&]() {
+#pragma unroll
+		for (int k = 0; k < 4 * NP; k++)
+			__builtin_amdgcn_raw_buffer_store_b32(0u, rs_stream, OOB, 0, 0);
+	};
+
+	// slots v_begin .. r_hi + 2; slot v consumes pixel rows 2 v, 2 v + 1 and finishes sub-band row v - 3.  The first six slots
+	// finish rows r_lo - 6 .. r_lo - 1, which belong to the segment above (or do not exist): no gate, quantizer or stores.
+	const int v_begin = r_lo - 3;
+	const int n_slots = r_hi + 3 - v_begin;
+	Raw ring;
+	fetch(v_begin, ring);
+	// lockstep: the waves of a workgroup (neighbouring strips, the pair even the same pixels) meet every six slots, so that
+	// what one brought into L2 is still there when its neighbour asks for it (StreamGeom::lockstep; always on here: a branch
+	// around the barrier makes the block behind it a place to sink the first trip's arithmetic into, through scratch)
+	__builtin_amdgcn_s_barrier();
+	static_for<6>([&](auto kc) {
+		constexpr int K = decltype(kc)::value;
+		float lp[NP][4], hp[NP][4];
+		lift_slot(kc, v_begin + K, ring, lp, hp);
+		(void)lp, (void)hp;
+		// Slot by slot: with nothing to store, nothing ties a slot's arithmetic to its place -- instruction selection then
+		// computes each value where it is first used, slots later, and parks what it needs until then in scratch.  The column
+		// pipeline's new entries are "used" here, the low-pass update that nobody reads stays dead.
+#pragma unroll
+		for (int p = 0; p < NP; p++)
+			asm volatile("" ::"v"(st[p][0].e[K % 3]), "v"(st[p][1].e[K % 3]), "v"(st[p][2].e[K % 3]), "v"(st[p][3].e[K % 3]),
+			             "v"(st[p][0].o[K % 2]), "v"(st[p][1].o[K % 2]), "v"(st[p][2].o[K % 2]), "v"(st[p][3].o[K % 2]),
+			             "v"(st[p][0].h[K % 3]), "v"(st[p][1].h[K % 3]), "v"(st[p][2].h[K % 3]), "v"(st[p][3].h[K % 3]));
+		__builtin_amdgcn_sched_barrier(0);
+		if constexpr (K == 5)
+			phantom_stores();
+	});
+	for (int base = 6; base < n_slots; base += 6)
+	{
+		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
+			asm volatile("; AKO_LOOP fwd_u8_lean_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+		__builtin_amdgcn_s_barrier();  // (lockstep, see above)
+		static_for<6>([&](auto kc) { full_slot(kc, v_begin + base + decltype(kc)::value, ring); });
+	}
+}
+
+template <int KIND, int CH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_forward_u8_lean(const LevelParams P, const StreamGeom G)
+{
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+#define AKO_FWD_LEAN(H, V)                                                   \
+	do                                                                       \
+	{                                                                        \
+		if (id.pg == 0)                                                      \
+			forward_u8_lean<KIND, CH, 0, H, V>(P, G, id, lc, lane);          \
+		else                                                                 \
+			forward_u8_lean<KIND, CH, 1, H, V>(P, G, id, lc, lane);          \
+	} while (0)
+	if (__builtin_expect(vedge, 0))
+	{
+		if (lc.hedge)
+			AKO_FWD_LEAN(true, true);
+		else
+			AKO_FWD_LEAN(false, true);
+	}
+	else
+	{
+		if (lc.hedge)
+			AKO_FWD_LEAN(true, false);
+		else
+			AKO_FWD_LEAN(false, false);
+	}
+#undef AKO_FWD_LEAN
+}
+
+}  // namespace ako

@@ -5,9 +5,13 @@
 namespace ako
 {
 
-void AKO_U8_NAME(akoLaunchForwardU8)(int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st)
+void AKO_U8_NAME(akoLaunchForwardU8)(int kind, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st)
 {
-	if (kind == K_DD137)
+	if (lean && kind == K_DD137)
+		hipLaunchKernelGGL((k_forward_u8_lean<K_DD137, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
+	else if (lean && kind == K_CDF53)
+		hipLaunchKernelGGL((k_forward_u8_lean<K_CDF53, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
+	else if (kind == K_DD137)
 		hipLaunchKernelGGL((k_forward_stream_u8<K_DD137, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
 	else if (kind == K_CDF53)
 		hipLaunchKernelGGL((k_forward_stream_u8<K_CDF53, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
@@ -28,9 +32,18 @@ static void launch_inverse(int kind, const LevelParams& P, const StreamGeom& G, 
 		hipLaunchKernelGGL((k_inverse_stream_u8<K_HAAR, OPT, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
 }
 
-void AKO_U8_NAME(akoLaunchInverseU8)(int kind, bool opt, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st)
+void AKO_U8_NAME(akoLaunchInverseU8)(int kind, bool opt, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st)
 {
-	if (opt)
+	if (opt && lean && kind != K_HAAR)  // (the lean kernel is the optimistic launch; the exact kernel behind it stays the general one)
+	{
+		const dim3 threads(128 * pairs);
+		const uint32_t lds = pairs * INV_U8_LDS_PER_PAIR;
+		if (kind == K_DD137)
+			hipLaunchKernelGGL((k_inverse_u8_lean<K_DD137, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
+		else
+			hipLaunchKernelGGL((k_inverse_u8_lean<K_CDF53, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
+	}
+	else if (opt)
 		launch_inverse<true>(kind, P, G, blocks, pairs, st);
 	else
 		launch_inverse<false>(kind, P, G, blocks, pairs, st);

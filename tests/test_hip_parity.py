@@ -43,13 +43,13 @@ def hip_decode_body(body, s, ch, w, h):
 
 
 @pytest.fixture(params=["auto", "generic", "stream", "generic-notail", "stream-notail", "stream-noopt",
-                        "stream-tail1", "stream-nostaged", "auto-fuse2", "stream-fuse2"])
+                        "stream-tail1", "stream-nostaged", "auto-fuse2", "stream-fuse2", "auto-nolean", "stream-nolean"])
 def path_mode(request):
     """AKO_HIP_PATH: 'generic' forces the LDS window engine, 'stream' forces the register-streaming
     kernels wherever they are legal (even at tiny sizes), 'auto' is what ships.  '-notail' also
     switches the fused in-LDS tail kernel off (AKO_HIP_TAIL=0) so every level runs as its own launch;
     '-noopt' runs the exact int16-wrapping inverse alone instead of optimistic fp32 + exact fallback."""
-    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE2")}
+    old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE2", "AKO_HIP_LEAN")}
     mode = request.param
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
     # AKO_HIP_TAIL: 0 no in-LDS tail, 1 (default) the window-engine tail
@@ -65,6 +65,8 @@ def path_mode(request):
     # '-fuse2': levels 0 and 1 of eligible RGBA plans in one workgroup walk per direction (the two-level kernels of
     # ako_fused.hip.h; off by default)
     os.environ["AKO_HIP_FUSE2"] = "3" if mode.endswith("-fuse2") else "0"
+    # '-nolean': the general u8 level-0 kernels everywhere (default: the lean kernels of ako_u8_lean.hip.h where they apply)
+    os.environ["AKO_HIP_LEAN"] = "0" if mode.endswith("-nolean") else "1"
     yield mode
     for k, v in old.items():
         if v is None:
