@@ -32,6 +32,9 @@
 namespace ako
 {
 
+#ifndef AKO_U8L_LOCKSTEP
+#define AKO_U8L_LOCKSTEP 1  // experiments: 0 = no lockstep barrier in the lean forward kernel
+#endif
 #ifndef AKO_U8L_INV_PF
 #define AKO_U8L_INV_PF 1  // row slots the lean inverse kernel fetches ahead (1 or 2; 2 measured no faster)
 #endif
@@ -43,34 +46,118 @@ constexpr float OPT_INPUT_BOUND_TIGHT = 1187.0f;
 constexpr int XI_PLANE = 4 * 64, XI_ROLE = 2 * XI_PLANE, XI_BUF = 2 * XI_ROLE;
 static_assert(2 * XI_BUF * sizeof(float) == INV_U8_LDS_PER_PAIR, "same LDS per pair as the general kernel");
 
+// ---- in-kernel phase stamps (measurement builds: scripts/build_rgba_variant.sh stamps -DAKO_STAMPS) --------------------
+// s_memtime between the phases of a row slot, per-phase sums kept in scalars and added to ako_lean_stamps[direction][phase]
+// by lane 0 when the wave ends (a row per wave: [9] counts waves, [8] sums wave lifetimes); scripts/issue_model.py reads them through
+// akoHipLeanStamps().  Every stamp first pins the values of the phase it closes (AKO_PIN: otherwise instruction selection
+// computes them where they are used, phases later).  The shipped library holds none of this.
+#ifdef AKO_STAMPS
+constexpr int STAMP_WAVES = 16384;  // (a row per wave: 8 000 waves adding to sixteen shared words serialise for a millisecond)
+__device__ unsigned long long ako_lean_stamps[2][STAMP_WAVES][12];  // [10], [11]: birth and end of the row's latest wave (absolute)
+// One slot in six is stamped (unroll position 0), and a slot's stamps are only read at its end: s_memtime answers through the
+// scalar cache after several hundred cycles, and a wave that waited for each answer where it asked ran four times as long.
+#define AKO_STAMP_DECL                                          \
+	unsigned long long st_acc[8] = {};                          \
+	unsigned long long st_t[8] = {};                            \
+	unsigned long long st_prev = __builtin_amdgcn_s_memtime();  \
+	const unsigned long long st_born = st_prev
+#define AKO_STAMP_K(i, K_)                                       \
+	do                                                           \
+	{                                                            \
+		if constexpr ((K_) == 0)                                 \
+		{                                                        \
+			__builtin_amdgcn_sched_barrier(0);                   \
+			st_t[i] = __builtin_amdgcn_s_memtime();              \
+			__builtin_amdgcn_sched_barrier(0);                   \
+		}                                                        \
+	} while (0)
+#define AKO_STAMP(i) AKO_STAMP_K(i, K)
+// the sampled slot's phases first .. last: st_prev = the stamp in front of phase `first`
+#define AKO_STAMP_SLOT_BEGIN(K_)                                 \
+	do                                                           \
+	{                                                            \
+		if constexpr ((K_) == 0)                                 \
+		{                                                        \
+			__builtin_amdgcn_sched_barrier(0);                   \
+			st_prev = __builtin_amdgcn_s_memtime();              \
+			__builtin_amdgcn_sched_barrier(0);                   \
+		}                                                        \
+	} while (0)
+#define AKO_STAMP_SLOT_END(K_, first, last)                      \
+	do                                                           \
+	{                                                            \
+		if constexpr ((K_) == 0)                                 \
+		{                                                        \
+			__builtin_amdgcn_sched_barrier(0);                   \
+			unsigned long long p_ = st_prev;                     \
+			for (int i_ = (first); i_ <= (last); i_++)           \
+				st_acc[i_] += st_t[i_] - p_, p_ = st_t[i_];      \
+			__builtin_amdgcn_sched_barrier(0);                   \
+		}                                                        \
+	} while (0)
+#define AKO_STAMP_NOW(i)                                                 \
+	do                                                                   \
+	{                                                                    \
+		__builtin_amdgcn_sched_barrier(0);                               \
+		const unsigned long long st_now = __builtin_amdgcn_s_memtime();  \
+		st_acc[i] += st_now - st_prev;                                   \
+		st_prev = st_now;                                                \
+		__builtin_amdgcn_sched_barrier(0);                               \
+	} while (0)
+#define AKO_STAMP_FLUSH(dir)                                                                                           \
+	do                                                                                                                 \
+	{                                                                                                                  \
+		if (lane == 0)                                                                                                 \
+		{                                                                                                              \
+			unsigned long long* row_ = ako_lean_stamps[dir][(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % STAMP_WAVES]; \
+			for (int i_ = 0; i_ < 8; i_++)                                                                             \
+				row_[i_] += st_acc[i_];                                                                                \
+			const unsigned long long st_end = __builtin_amdgcn_s_memtime();                                            \
+			row_[8] += st_end - st_born;                                                                               \
+			row_[9] += 1ull;                                                                                           \
+			row_[10] = st_born, row_[11] = st_end;                                                                     \
+		}                                                                                                              \
+	} while (0)
+#define AKO_PIN4(a) asm volatile("" ::"v"((a)[0]), "v"((a)[1]), "v"((a)[2]), "v"((a)[3]))
+#define AKO_WAIT_VM(n, K_)                                                                   \
+	do                                                                                       \
+	{                                                                                        \
+		if constexpr ((K_) == 0)                                                             \
+			__builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));             \
+	} while (0)
+#else
+#define AKO_STAMP_DECL
+#define AKO_STAMP(i)
+#define AKO_STAMP_K(i, K_)
+#define AKO_STAMP_SLOT_BEGIN(K_)
+#define AKO_STAMP_SLOT_END(K_, first, last)
+#define AKO_STAMP_NOW(i)
+#define AKO_STAMP_FLUSH(dir)
+#define AKO_PIN4(a)
+#define AKO_WAIT_VM(n, K_)
+#endif
+
 // ---- left / right tile border without control flow (CLAMP and ZERO) -----------------------------------------------
-// fix_halo_lanes() (ako_stream.hip.h) asks per side whether the strip has lanes beyond the border and branches around the
-// patch; with eight row lifts per slot that cut the slot into a hundred basic blocks.  Here both sides are patched
-// unconditionally: two v_readlane + four v_cndmask per sequence, with lane masks that are simply empty on a side without
-// such lanes.  CLAMP takes the nearest in-range value, ZERO zero (wavelet-dd137.c:76-79,110-125); REPEAT strips never have
-// such lanes (they wrap their load addresses, lane_columns()) and run the bodies without border code.
+// fix_halo_lanes() (ako_stream.hip.h) overwrites the lanes BEYOND a border with the nearest in-range value (or zero), per
+// sequence and side, behind a branch: eight row lifts per slot cut the slot into a hundred basic blocks, and a strip at a tile
+// border ran 2.4-3 x the instructions of an interior one.  Its waves -- and, through the lockstep barriers, their whole
+// workgroup -- were the tail of every launch.  The lanes beyond a border are only ever read by ONE lane, the first / last one
+// inside (DD13/7 taps reach two columns = one lane), so here that lane's taps are substituted instead and the lanes beyond
+// compute garbage that nobody reads or stores: three selects per side and row lift on per-lane masks that are simply empty in
+// a strip without that border.  CLAMP: E[-1] := E[0]; HP[-1] = HP[-2] := HP[0]; E[T] = E[T+1] := E[T-1]; HP[T] := HP[T-1]
+// (wavelet-dd137.c:76-79,110-125), ZERO: zeros.  REPEAT strips have no such lanes (they wrap their load addresses,
+// lane_columns()) and run the bodies without border code; MIRROR stays on the general kernels.
 struct HEdgeBF
 {
-	bool oob_l, oob_r;          // this lane lies beyond the left / right border
-	int lane_first, lane_last;  // the lanes that hold columns 0,1 / T-2,T-1 (any valid lane on a side without border)
-	bool zero;                  // W_ZERO
+	bool first, last;  // this lane holds columns 0,1 / T-2,T-1 of a tile whose border rule is CLAMP or ZERO
+	bool zero;         // W_ZERO
 };
 __device__ __forceinline__ HEdgeBF hedge_bf(const HEdge& he)
 {
 	HEdgeBF e;
-	e.oob_l = he.left && he.oob_l, e.oob_r = he.right && he.oob_r;
-	e.lane_first = he.lane_first & 63, e.lane_last = min(max(he.lane_last, 0), 63);
+	e.first = he.left && he.first, e.last = he.right && he.last;
 	e.zero = he.wrap == W_ZERO;
 	return e;
-}
-template <typename V>
-__device__ __forceinline__ void fix_halo_lanes_bf(V& a0, V& a1, const HEdgeBF& e)
-{
-	V fl = read_lane(a0, e.lane_first), fr = read_lane(a1, e.lane_last);
-	if (e.zero)  // wave-uniform: scalar selects
-		fl = (V)0, fr = (V)0;
-	a0 = e.oob_l ? fl : a0, a1 = e.oob_l ? fl : a1;
-	a0 = e.oob_r ? fr : a0, a1 = e.oob_r ? fr : a1;
 }
 // A neighbour tap that feeds TWO sums: kept as one DPP move whose result the compiler may not fold away again.  Left alone it
 // folds the tap into one of its consumers (a DPP add issues at the rate of a DPP move, half that of a plain add) and still
@@ -81,25 +168,35 @@ __device__ __forceinline__ V keep_tap(V x)
 	asm("" : "+v"(x));
 	return x;
 }
-// hlift_inverse() / hlift_forward() of ako_stream.hip.h with that border patch (HB = false: none at all)
+// hlift_inverse() / hlift_forward() of ako_stream.hip.h with that border rule (HB = false: none at all)
 template <int KIND, bool HB, typename V>
 __device__ __forceinline__ void hlift_inverse_bf(V L0, V L1, V H0, V H1, const HEdgeBF& e, V& E0, V& O0, V& E1, V& O1)
 {
 	static_assert(KIND != K_HAAR, "lifting wavelets");
-	if constexpr (HB)
-		fix_halo_lanes_bf(H0, H1, e);
-	const V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
+	V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
 	V hL0 = (V)0, hR0 = (V)0;
 	if constexpr (KIND == K_DD137)
 		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : H0, hi = e.zero ? (V)0 : H1;
+		hL1 = e.first ? lo : hL1;
+		if constexpr (KIND == K_DD137)
+			hL0 = e.first ? lo : hL0, hR0 = e.last ? hi : hR0;
+	}
 	E0 = lift_add<false>(L0, sum_u<KIND, -1>(hL0, hL1, H0, H1), shift_u<KIND>());
 	E1 = lift_add<false>(L1, sum_u<KIND, -1>(hL1, H0, H1, hR0), shift_u<KIND>());
-	if constexpr (HB)
-		fix_halo_lanes_bf(E0, E1, e);
-	const V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
+	V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
 	V eL = (V)0, eR1 = (V)0;
 	if constexpr (KIND == K_DD137)
 		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : E0, hi = e.zero ? (V)0 : E1;
+		eR0 = e.last ? hi : eR0;
+		if constexpr (KIND == K_DD137)
+			eL = e.first ? lo : eL, eR1 = e.last ? hi : eR1;
+	}
 	O0 = lift_add<false>(H0, sum_p<KIND, -1>(eL, E0, E1, eR0), shift_p<KIND>());
 	O1 = lift_add<false>(H1, sum_p<KIND, -1>(E0, E1, eR0, eR1), shift_p<KIND>());
 }
@@ -107,20 +204,30 @@ template <int KIND, bool HB, typename V>
 __device__ __forceinline__ void hlift_forward_bf(V E0, V O0, V E1, V O1, const HEdgeBF& e, V& L0, V& L1, V& H0, V& H1)
 {
 	static_assert(KIND != K_HAAR, "lifting wavelets");
-	if constexpr (HB)
-		fix_halo_lanes_bf(E0, E1, e);
-	const V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
+	V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
 	V eL = (V)0, eR1 = (V)0;
 	if constexpr (KIND == K_DD137)
 		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : E0, hi = e.zero ? (V)0 : E1;
+		eR0 = e.last ? hi : eR0;
+		if constexpr (KIND == K_DD137)
+			eL = e.first ? lo : eL, eR1 = e.last ? hi : eR1;
+	}
 	H0 = lift_add<false>(O0, sum_p<KIND, +1>(eL, E0, E1, eR0), shift_p<KIND>());
 	H1 = lift_add<false>(O1, sum_p<KIND, +1>(E0, E1, eR0, eR1), shift_p<KIND>());
-	if constexpr (HB)
-		fix_halo_lanes_bf(H0, H1, e);
-	const V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
+	V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
 	V hL0 = (V)0, hR0 = (V)0;
 	if constexpr (KIND == K_DD137)
 		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : H0, hi = e.zero ? (V)0 : H1;
+		hL1 = e.first ? lo : hL1;
+		if constexpr (KIND == K_DD137)
+			hL0 = e.first ? lo : hL0, hR0 = e.last ? hi : hR0;
+	}
 	L0 = lift_add<false>(E0, sum_u<KIND, +1>(hL0, hL1, H0, H1), shift_u<KIND>());
 	L1 = lift_add<false>(E1, sum_u<KIND, +1>(hL1, H0, H1, hR0), shift_u<KIND>());
 }
@@ -260,6 +367,8 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	float peak_in = 0.0f;
 	const HEdgeBF he = hedge_bf(lc.he);
 	const VEdgeBF ve = {wrap != W_REPEAT, wrap == W_ZERO};
+	AKO_STAMP_DECL;  // phases: 0 wait for the slot's coefficients, 1 unpack + column pass, 2 row pass, 3 LDS writes + barrier,
+	                 // 4 LDS reads, 5 colour + pack, 6 store, 7 the first trip (pipeline fill)
 
 	struct Raw
 	{
@@ -316,7 +425,18 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	auto full_slot = [&](auto kc, const int v, const Raw& raw) {
 		constexpr int K = decltype(kc)::value;
 		float ev[NP][4], od[NP][4];
+		AKO_STAMP_SLOT_BEGIN(K);
+		AKO_WAIT_VM(4 * NP * AKO_U8L_INV_PF + 1, K);  // (stamps: everything but the slots fetched ahead and the last pixel store)
+		AKO_STAMP(0);
 		column_pass(kc, v, raw, ev, od);
+#ifdef AKO_STAMPS
+		for (int p = 0; p < NP; p++)
+		{
+			AKO_PIN4(ev[p]);
+			AKO_PIN4(od[p]);
+		}
+#endif
+		AKO_STAMP(1);
 		// row pass: this wave finishes pixel row ROLE of the slot (role 0 the even one), the other row's planes go to the partner
 		float mine[NP][4], send[NP][4];
 #pragma unroll
@@ -334,17 +454,33 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 				hlift_inverse_bf<KIND, HEDGE, float>(ev[p][0], ev[p][1], ev[p][2], ev[p][3], he, sd[0], sd[1], sd[2], sd[3]);
 				hlift_inverse_bf<KIND, HEDGE, float>(od[p][0], od[p][1], od[p][2], od[p][3], he, me[0], me[1], me[2], me[3]);
 			}
+		}
+#ifdef AKO_STAMPS
+		for (int p = 0; p < NP; p++)
+		{
+			AKO_PIN4(mine[p]);
+			AKO_PIN4(send[p]);
+		}
+#endif
+		AKO_STAMP(2);
+#pragma unroll
+		for (int p = 0; p < NP; p++)
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				xw[(K & 1) * XI_BUF + p * XI_PLANE + k * 64] = sd[k];
-		}
+				xw[(K & 1) * XI_BUF + p * XI_PLANE + k * 64] = send[p][k];
 		__syncthreads();  // (one barrier per slot, double buffered: see inverse_stream_body)
+		AKO_STAMP(3);
 		float his[2][4] = {};
 #pragma unroll
 		for (int p = 0; p < NP_HIS; p++)
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 				his[p][k] = xr[(K & 1) * XI_BUF + p * XI_PLANE + k * 64];
+#ifdef AKO_STAMPS
+		for (int p = 0; p < NP_HIS; p++)
+			AKO_PIN4(his[p]);
+#endif
+		AKO_STAMP(4);
 
 		const int r = v - 3, y = 2 * r + ROLE;
 		const bool row_ok = (r >= r_lo) && (r < r_hi) && (y < oh);  // wave-uniform; phantom last row dropped (lifting.c:112,141)
@@ -372,6 +508,8 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 			const float rr = bb + co;
 			px[k] = pixel_u8x4(rr, gg, bb, al);
 		}
+		AKO_PIN4(px);
+		AKO_STAMP(5);
 		const uint32_t s_row = row_ok ? (uint32_t)y * out_pitch_b : OOB;
 		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 		if constexpr (CH == 3)
@@ -379,6 +517,8 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 		else
 			__builtin_amdgcn_raw_buffer_store_b128(u32x4{px[0], px[1], px[2], px[3]}, rs_img, px_lane_off, s_row, AUX_INV_PIXEL_STORE);
 		AKO_STORE_GUARD();  // (see store_b128_guarded)
+		AKO_STAMP(6);
+		AKO_STAMP_SLOT_END(K, 0, 6);
 	};
 
 	// slots v_begin .. r_hi + 2; slot v consumes quadrant row v and finishes sample rows 2 (v - 3), 2 (v - 3) + 1.  The first six
@@ -405,6 +545,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 		if constexpr (K == 5)
 			__builtin_amdgcn_raw_buffer_store_b32(0u, rs_img, OOB, 0, 0);
 	});
+	AKO_STAMP_NOW(7);
 	for (int base = 6; base < n_slots; base += 6)
 	{
 		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
@@ -420,6 +561,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	const bool bad = !(peak_in <= OPT_INPUT_BOUND_TIGHT);  // negated: NaN counts as bad
 	if (__any(bad) && lane == 0)
 		atomicMax(P.ovf_flag, P.ovf_gen);
+	AKO_STAMP_FLUSH(1);
 }
 
 // the workgroup is 1, 2 or 4 pairs of waves (neighbouring strips); 8 KiB of dynamic LDS per pair, as k_inverse_stream_u8
@@ -524,6 +666,8 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 			st[p][k] = VFwd<float>{{0, 0, 0}, {0, 0}, {0, 0, 0}};
 	const HEdgeBF he = hedge_bf(lc.he);
 	const VEdgeBF ve = {wrap != W_REPEAT, wrap == W_ZERO};
+	AKO_STAMP_DECL;  // phases: 0 wait for the slot's pixels, 1 pixels -> samples, 2 row pass, 3 column pass, 4 gate + quantizer + pack,
+	                 // 5 stores, 6 the barrier of a trip, 7 the first trip (pipeline fill)
 
 	struct Raw
 	{
@@ -552,6 +696,9 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 		constexpr int K = decltype(kc)::value;
 		const bool zero_row = VEDGE && ve.zero && ((unsigned)v >= (unsigned)Tr);
 		float smp[2][2][4];
+		AKO_STAMP_SLOT_BEGIN(K);
+		AKO_WAIT_VM(4 * NP, K);  // (stamps: everything but the previous slot's stores)
+		AKO_STAMP(0);
 #pragma unroll
 		for (int par = 0; par < 2; par++)
 		{
@@ -569,22 +716,51 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 				for (int k = 0; k < 4; k++)
 					smp[par][0][k] = zero_row ? 0.0f : smp[par][0][k], smp[par][1][k] = zero_row ? 0.0f : smp[par][1][k];
 		}
+#ifdef AKO_STAMPS
+		for (int p = 0; p < NP; p++)
+		{
+			AKO_PIN4(smp[0][p]);
+			AKO_PIN4(smp[1][p]);
+		}
+#endif
+		AKO_STAMP(1);
 		// the slot's pixels are samples now: the next slot's go into the registers they left
 		__builtin_amdgcn_sched_barrier(0);
 		fetch(v + 1, raw);
 		__builtin_amdgcn_sched_barrier(0);
+		float e[NP][4], o[NP][4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
 #pragma unroll
 		for (int p = 0; p < NP; p++)
 		{
-			float e[4], o[4];  // columns: 0,1 = row low-pass of c0, c1; 2,3 = row high-pass of c0, c1
-			hlift_forward_bf<KIND, HEDGE, float>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], he, e[0], e[1], e[2], e[3]);
-			hlift_forward_bf<KIND, HEDGE, float>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], he, o[0], o[1], o[2], o[3]);
+			hlift_forward_bf<KIND, HEDGE, float>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], he, e[p][0], e[p][1], e[p][2], e[p][3]);
+			hlift_forward_bf<KIND, HEDGE, float>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], he, o[p][0], o[p][1], o[p][2], o[p][3]);
+#ifndef AKO_STAMPS
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[k], o[k], v, ve, Tr, lp[p][k], hp[p][k]);
+				vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+#endif
 		}
+#ifdef AKO_STAMPS
+		for (int p = 0; p < NP; p++)
+		{
+			AKO_PIN4(e[p]);
+			AKO_PIN4(o[p]);
+		}
+		AKO_STAMP(2);
+		for (int p = 0; p < NP; p++)
+			for (int k = 0; k < 4; k++)
+				vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+		for (int p = 0; p < NP; p++)
+		{
+			AKO_PIN4(lp[p]);
+			AKO_PIN4(hp[p]);
+		}
+		AKO_STAMP(3);
+#endif
 	};
 	auto full_slot = [&](auto kc, const int v, Raw& raw) {
+		constexpr int K = decltype(kc)::value;
+		(void)K;
 		float lp[NP][4], hp[NP][4];
 		lift_slot(kc, v, raw, lp, hp);
 		const int r = v - 3;
@@ -596,6 +772,11 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 			// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP); gate + quantizer: lifting.c:154-168
 			uint32_t w_ll, w_c, w_b, w_d;
 			pack_row_f(lp[p], hp[p], gf[p], rq[p], w_ll, w_c, w_b, w_d);
+#ifdef AKO_STAMPS
+			asm volatile("" ::"v"(w_ll), "v"(w_c), "v"(w_b), "v"(w_d));
+			if (p == NP - 1)
+				AKO_STAMP(4);
+#endif
 			const uint32_t s_ll = row_ok ? ll_off[p] + row_ll : OOB;
 			const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
 			const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
@@ -605,6 +786,8 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 			__builtin_amdgcn_raw_buffer_store_b32(w_b, rs_stream, lane_off, s_b, AUX_FWD_STREAM_STORE);
 			__builtin_amdgcn_raw_buffer_store_b32(w_d, rs_stream, lane_off, s_d, AUX_FWD_STREAM_STORE);
 		}
+		AKO_STAMP(5);
+		AKO_STAMP_SLOT_END(K, 0, 5);
 	};
 	// (dropped) stores: as many as a full slot issues, so that the memory operations in flight look the same on entry to the
 	// main loop as on every later trip (stores count in vmcnt on gfx950)
@@ -623,7 +806,8 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 	// lockstep: the waves of a workgroup (neighbouring strips, the pair even the same pixels) meet every six slots, so that
 	// what one brought into L2 is still there when its neighbour asks for it (StreamGeom::lockstep; always on here: a branch
 	// around the barrier makes the block behind it a place to sink the first trip's arithmetic into, through scratch)
-	__builtin_amdgcn_s_barrier();
+	if constexpr (AKO_U8L_LOCKSTEP != 0)
+		__builtin_amdgcn_s_barrier();
 	static_for<6>([&](auto kc) {
 		constexpr int K = decltype(kc)::value;
 		float lp[NP][4], hp[NP][4];
@@ -645,9 +829,15 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 	{
 		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
 			asm volatile("; AKO_LOOP fwd_u8_lean_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
-		__builtin_amdgcn_s_barrier();  // (lockstep, see above)
+		if (base == 6)
+			AKO_STAMP_NOW(7);
+		AKO_STAMP_SLOT_BEGIN(0);
+		if constexpr (AKO_U8L_LOCKSTEP != 0)
+			__builtin_amdgcn_s_barrier();  // (lockstep, see above)
+		AKO_STAMP_NOW(6);
 		static_for<6>([&](auto kc) { full_slot(kc, v_begin + base + decltype(kc)::value, ring); });
 	}
+	AKO_STAMP_FLUSH(0);
 }
 
 template <int KIND, int CH>

@@ -50,3 +50,43 @@ void AKO_U8_NAME(akoLaunchInverseU8)(int kind, bool opt, bool lean, const LevelP
 }
 
 }  // namespace ako
+
+#if defined(AKO_STAMPS) && AKO_U8_CH == 4
+// measurement builds: the phase sums of the lean kernels (ako_u8_lean.hip.h) summed over the waves, 2 x 10 values; reset != 0
+// clears them afterwards
+extern "C" __attribute__((visibility("default"))) int akoHipLeanStamps(unsigned long long* out, int reset)
+{
+	const size_t n = (size_t)2 * ako::STAMP_WAVES * 12;
+	unsigned long long* h = (unsigned long long*)calloc(n, sizeof(unsigned long long));
+	if (h == nullptr || hipMemcpyFromSymbol(h, HIP_SYMBOL(ako::ako_lean_stamps), n * sizeof(unsigned long long)) != hipSuccess)
+	{
+		free(h);
+		return 1;
+	}
+	for (int d = 0; d < 2; d++)
+		for (int i = 0; i < 10; i++)
+		{
+			unsigned long long sum = 0;
+			for (int w = 0; w < ako::STAMP_WAVES; w++)
+				sum += h[((size_t)d * ako::STAMP_WAVES + w) * 12 + i];
+			out[d * 10 + i] = sum;
+		}
+	// behind the sums: birth and end of every row's latest wave (2 x STAMP_WAVES x 2 values), if the caller left room for them
+	if (reset & 2)
+		for (int d = 0; d < 2; d++)
+			for (int w = 0; w < ako::STAMP_WAVES; w++)
+			{
+				out[20 + ((size_t)d * ako::STAMP_WAVES + w) * 2 + 0] = h[((size_t)d * ako::STAMP_WAVES + w) * 12 + 10];
+				out[20 + ((size_t)d * ako::STAMP_WAVES + w) * 2 + 1] = h[((size_t)d * ako::STAMP_WAVES + w) * 12 + 11];
+			}
+	int rc = 0;
+	if (reset & 1)
+	{
+		for (size_t i = 0; i < n; i++)
+			h[i] = 0;
+		rc = hipMemcpyToSymbol(HIP_SYMBOL(ako::ako_lean_stamps), h, n * sizeof(unsigned long long)) != hipSuccess;
+	}
+	free(h);
+	return rc;
+}
+#endif

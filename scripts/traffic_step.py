@@ -1,6 +1,6 @@
 """Exactly STEPS (default 4) encode + decode steps of one bench workload on one plan, nothing else: the program
 scripts/collect_traffic.sh puts under rocprofv3 --pmc, so that 'bytes per step' is the counter total / STEPS.
-usage: traffic_step.py [full8192 | rgb8192 | batch4k | lift4096 | tiles16k_512 | tiles16k_256]"""
+usage: traffic_step.py [full8192 | full8192x4 | rgb8192 | batch4k | lift4096 | tiles16k_512 | tiles16k_256]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,8 @@ steps = int(os.environ.get("STEPS", "4"))
 planes = False
 if wl == "full8192":
     w, h, ch, batch, s = 8192, 8192, 4, 1, api.settings(wavelet=0, compression=2, q=16, g=16)
+elif wl == "full8192x4":  # four images per launch: dispatches of 0.8 ms (scripts/collect_clock.sh: GRBM_GUI_ACTIVE reads high on short ones)
+    w, h, ch, batch, s = 8192, 8192, 4, 4, api.settings(wavelet=0, compression=2, q=16, g=16)
 elif wl == "rgb8192":
     w, h, ch, batch, s = 8192, 8192, 3, 1, api.settings(wavelet=0, compression=2, q=16, g=16)
 elif wl == "batch4k":
