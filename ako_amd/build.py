@@ -14,8 +14,8 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libako.so")
-OBJ = os.path.join(HERE, "csrc", "build")
+OUT = os.path.join(HERE, "libako_experimental.so" if os.environ.get("AKO_BUILD_EXPERIMENTAL") == "1" else "libako.so")
+OBJ = os.path.join(HERE, "csrc", "build_experimental" if os.environ.get("AKO_BUILD_EXPERIMENTAL") == "1" else "build")
 
 # translation units of device code and the headers each one includes (they build in parallel: ako_plan.hip alone takes minutes)
 HIP_SOURCES = {
@@ -23,9 +23,15 @@ HIP_SOURCES = {
                      "ako_requant.hip.h", "ako_fused.h", "ako_u8.h"],
     "ako_u8_rgba.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8_lean.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
     "ako_u8_rgb.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8_lean.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
-    "ako_u8_group.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8.h"],
-    "ako_fused.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_fused.h", "ako_fused.hip.h"],
+    "ako_copy.hip": [],
 }
+# The routes that lost their measurements (levels 0 + 1 in one workgroup walk, AKO_HIP_FUSE2; level 0 in column groups with
+# whole-line stores, AKO_HIP_GROUP) stay in the source and are parity-tested, but only a build with AKO_BUILD_EXPERIMENTAL=1
+# holds them (-DAKO_EXPERIMENTAL in every unit; objects and library get their own names so that both builds can coexist).
+EXPERIMENTAL = os.environ.get("AKO_BUILD_EXPERIMENTAL") == "1"
+if EXPERIMENTAL:
+    HIP_SOURCES["ako_u8_group.hip"] = ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8.h"]
+    HIP_SOURCES["ako_fused.hip"] = ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_fused.h", "ako_fused.hip.h"]
 C_SOURCES = ["host/ako_quant.c", "host/ako_head.c", "host/ako_misc.c", "host/ako_kagari.c", "host/ako_codec.c",
              "host/ako_synth.c", "host/ako_batch.c"]
 C_HEADERS = ["host/ako_host.h", "../../include/ako.h", "../../include/ako_hip.h"]
@@ -61,7 +67,7 @@ def build(force: bool = False, extra_hip_flags: list[str] | None = None) -> str:
                     "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
                     # keeps the unit's device assembly beside the object (build/<unit>-hip-amdgcn-amd-amdhsa-gfx950.s):
                     # scripts/isa_lint.py and tests/test_isa_lint.py read the hot loops out of it
-                    "-save-temps=obj"] + (extra_hip_flags or []) +
+                    "-save-temps=obj"] + (["-DAKO_EXPERIMENTAL"] if EXPERIMENTAL else []) + (extra_hip_flags or []) +
                    os.environ.get("AKO_HIPCC_EXTRA", "").split() +  # experiments only
                    ["-c", os.path.join(CSRC, src), "-o", o])
             print(" ".join(cmd), flush=True)

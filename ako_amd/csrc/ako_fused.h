@@ -85,7 +85,8 @@ __host__ __device__ inline void f2_segment_rows(const F2Params& P, uint32_t seg,
 }
 
 // launchers (ako_fused.hip); kind = K_DD137 or K_CDF53
-void akoFused2ForwardLaunch(int kind, const F2Params& P, hipStream_t st);
-void akoFused2InverseLaunch(int kind, const F2Params& P, hipStream_t st);
+// (0, or nonzero when the launch could not be prepared; without AKO_EXPERIMENTAL the library holds stubs that are never called)
+int akoFused2ForwardLaunch(int kind, const F2Params& P, hipStream_t st);
+int akoFused2InverseLaunch(int kind, const F2Params& P, hipStream_t st);
 
 }  // namespace ako

@@ -1,7 +1,9 @@
-// ako_fused.hip -- the two-level workgroup kernels (ako_fused.hip.h) as a translation unit of their own, so that
-// they build in parallel with ako_plan.hip; the plan code calls the launchers declared in ako_fused.h.
+// ako_fused.hip -- the two-level workgroup kernels (ako_fused.hip.h) as a translation unit of their own; the plan code calls
+// the launchers declared in ako_fused.h.  EXPERIMENTAL: built only with AKO_BUILD_EXPERIMENTAL=1 (ako_amd/build.py); the
+// default library does not hold these kernels (measured slower than the level-per-kernel launches).
 #include "ako_fused.hip.h"
 
+#include <atomic>
 #include <stdlib.h>
 
 namespace ako
@@ -18,7 +20,7 @@ static uint32_t f2_dbg()
 #define F2_WITH_DBG(P) const F2Params& P##_use = P
 #endif
 
-void akoFused2ForwardLaunch(int kind, const F2Params& P_in, hipStream_t st)
+int akoFused2ForwardLaunch(int kind, const F2Params& P_in, hipStream_t st)
 {
 	F2_WITH_DBG(P_in);
 	const F2Params& P = P_in_use;
@@ -27,83 +29,32 @@ void akoFused2ForwardLaunch(int kind, const F2Params& P_in, hipStream_t st)
 		hipLaunchKernelGGL((k_fused2_forward<K_DD137>), dim3(blocks), dim3(F2_THREADS), 0, st, P);
 	else
 		hipLaunchKernelGGL((k_fused2_forward<K_CDF53>), dim3(blocks), dim3(F2_THREADS), 0, st, P);
+	return 0;
 }
 
-void akoFused2InverseLaunch(int kind, const F2Params& P_in, hipStream_t st)
+int akoFused2InverseLaunch(int kind, const F2Params& P_in, hipStream_t st)
 {
 	F2_WITH_DBG(P_in);
 	const F2Params& P = P_in_use;
-	static bool raised = false;  // 143 KiB of the CU's 160 KiB: beyond HIP's 64 KiB default
-	if (!raised)
+	// 143 KiB of the CU's 160 KiB: beyond HIP's 64 KiB default.  The attribute belongs to the device and function: raised once
+	// per device (a plan's launches come from one thread at a time, but several plans may start at once: atomics)
+	static std::atomic<int> raised[64];
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev >= 0 && dev < 64 && raised[dev].load(std::memory_order_acquire) == 0)
 	{
-		(void)hipFuncSetAttribute((const void*)k_fused2_inverse<K_DD137>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2I_LDS_BYTES);
-		(void)hipFuncSetAttribute((const void*)k_fused2_inverse<K_CDF53>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2I_LDS_BYTES);
-		raised = true;
+		const hipError_t e1 = hipFuncSetAttribute((const void*)k_fused2_inverse<K_DD137>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2I_LDS_BYTES);
+		const hipError_t e2 = hipFuncSetAttribute((const void*)k_fused2_inverse<K_CDF53>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F2I_LDS_BYTES);
+		if (e1 != hipSuccess || e2 != hipSuccess)
+			return 1;  // (the caller reports it: the launch would fail for want of LDS)
+		raised[dev].store(1, std::memory_order_release);
 	}
 	const uint32_t blocks = P.groups * P.segs * P.n_tiles * P.batch;
 	if (kind == K_DD137)
 		hipLaunchKernelGGL((k_fused2_inverse<K_DD137>), dim3(blocks), dim3(F2_THREADS), F2I_LDS_BYTES, st, P);
 	else
 		hipLaunchKernelGGL((k_fused2_inverse<K_CDF53>), dim3(blocks), dim3(F2_THREADS), F2I_LDS_BYTES, st, P);
-}
-
-// ---- the device's practical copy rate (the yardstick bench.py reports beside the 8 TB/s spec peak) ----
-// Four independent 16-byte loads in flight per lane before the first store, non-temporal both ways, every workgroup on
-// consecutive 16 KiB pieces: 5.3-5.9 TB/s read + write on MI355X where a one-load-in-flight grid-stride copy and
-// hipMemcpyAsync reach 4.6-5.1 (profiles/r3_hbm_rates.txt).
-typedef uint32_t copy_u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_tuned_copy(const copy_u32x4* __restrict__ in, copy_u32x4* __restrict__ out, size_t n)
-{
-	constexpr int U = 4;
-	const size_t per_block = (size_t)blockDim.x * U;
-	for (size_t base = blockIdx.x * per_block; base < n; base += (size_t)gridDim.x * per_block)
-	{
-		copy_u32x4 v[U];
-#pragma unroll
-		for (int u = 0; u < U; u++)
-		{
-			const size_t i = base + (size_t)u * blockDim.x + threadIdx.x;
-			v[u] = (i < n) ? __builtin_nontemporal_load(&in[i]) : copy_u32x4{0, 0, 0, 0};
-		}
-#pragma unroll
-		for (int u = 0; u < U; u++)
-		{
-			const size_t i = base + (size_t)u * blockDim.x + threadIdx.x;
-			if (i < n)
-				__builtin_nontemporal_store(v[u], &out[i]);
-		}
-	}
+	return 0;
 }
 
 }  // namespace ako
-
-// read + write GB/s of a device-to-device copy of `bytes` (two buffers of that size are allocated and freed); 0 on failure
-extern "C" __attribute__((visibility("default"))) double akoHipTunedCopyGBps(size_t bytes, int repeats)
-{
-	void *a = nullptr, *b = nullptr;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	double rate = 0.0;
-	if (bytes < 4096 || repeats < 1)
-		return 0.0;
-	if (hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess && hipMemset(a, 1, bytes) == hipSuccess &&
-	    hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
-	{
-		const size_t n = bytes / 16;
-		auto launch = [&] { hipLaunchKernelGGL(ako::k_tuned_copy, dim3(16384), dim3(256), 0, 0, (const ako::copy_u32x4*)a, (ako::copy_u32x4*)b, n); };
-		launch();
-		(void)hipEventRecord(e0, 0);
-		for (int i = 0; i < repeats; i++)
-			launch();
-		(void)hipEventRecord(e1, 0);
-		float ms = 0.0f;
-		if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f)
-			rate = 2.0 * (double)(n * 16) * repeats / (ms * 1e-3) / 1e9;
-	}
-	if (e0)
-		(void)hipEventDestroy(e0);
-	if (e1)
-		(void)hipEventDestroy(e1);
-	(void)hipFree(a);
-	(void)hipFree(b);
-	return rate;
-}

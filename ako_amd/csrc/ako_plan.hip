@@ -118,6 +118,18 @@ struct KagariState
 
 }  // namespace
 
+#ifndef AKO_EXPERIMENTAL
+// The default library is built without ako_fused.hip and ako_u8_group.hip: the routes that lost stay in the
+// source, parity-tested in an AKO_BUILD_EXPERIMENTAL=1 build, and out of libako.so.  Their launchers are never reached here
+// (Tuning::from_env keeps fuse2 and group at 0).
+namespace ako
+{
+int akoFused2ForwardLaunch(int, const F2Params&, hipStream_t) { return 1; }
+int akoFused2InverseLaunch(int, const F2Params&, hipStream_t) { return 1; }
+void akoLaunchForwardGroupU8_rgba(int, const LevelParams&, const StreamGeom&, uint32_t, hipStream_t) {}
+}  // namespace ako
+#endif
+
 // Tuning / test knobs, read from the environment ONCE when a plan is created (a launch path that called getenv per
 // level and call was neither cheap for small images nor safe against a concurrent setenv).
 struct Tuning
@@ -192,9 +204,15 @@ struct Tuning
 		if (t.inv_pairs != 1 && t.inv_pairs != 4)
 			t.inv_pairs = 2;
 		t.fuse2 = num("AKO_HIP_FUSE2", 0) & 3;
+#ifndef AKO_EXPERIMENTAL  // the default library holds neither the two-level kernels nor the column-group kernel (ako_amd/build.py)
+		t.fuse2 = 0;
+#endif
 		t.pack = num("AKO_HIP_PACK", 1) != 0;
 		t.row_strips = num("AKO_HIP_ROW_STRIPS", 1) != 0;
 		t.group = num("AKO_HIP_GROUP", 0);
+#ifndef AKO_EXPERIMENTAL
+		t.group = 0;
+#endif
 		t.group_min = num("AKO_HIP_GROUP_MIN", 1024);
 		t.f2_rows = num("AKO_HIP_F2_ROWS", 0);
 		t.f2_edge = num("AKO_HIP_F2_EDGE", -1);
@@ -992,7 +1010,8 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				Launch LF{pl, 0};
 				if (int rc = LF.begin())
 					return rc;
-				akoFused2ForwardLaunch(L.kind, F, pl->stream);
+				if (akoFused2ForwardLaunch(L.kind, F, pl->stream) != 0)
+					return fail(AKO_ERROR, "two-level forward launch could not be prepared%s%s");
 				char fname[48];
 				snprintf(fname, sizeof fname, "fwd_fused2_%s_u8", kind_name(L.kind));
 				const uint64_t smp0 = (uint64_t)L.cw * L.ch * pl->channels * insts;
@@ -1172,7 +1191,8 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				Launch LF{pl, 1};
 				if (int rc = LF.begin())
 					return rc;
-				akoFused2InverseLaunch(L.kind, F, pl->stream);
+				if (akoFused2InverseLaunch(L.kind, F, pl->stream) != 0)
+					return fail(AKO_ERROR, "two-level inverse launch could not be prepared (dynamic LDS limit)%s%s");
 				char fname[48];
 				snprintf(fname, sizeof fname, "inv_fused2_%s_u8", kind_name(L.kind));
 				const LevelGeom& L0 = g.levels[0];
@@ -1329,6 +1349,17 @@ static int guarded(F&& body)
 
 #pragma GCC visibility push(default)
 extern "C" {
+
+// 1 when the library was built with AKO_BUILD_EXPERIMENTAL=1: AKO_HIP_FUSE2 / AKO_HIP_GROUP then select the two-level workgroup
+// kernels (ako_fused.hip.h) and the column-group level-0 kernel (k_forward_group_u8); 0: those knobs are ignored
+int akoHipHasExperimental(void)
+{
+#ifdef AKO_EXPERIMENTAL
+	return 1;
+#else
+	return 0;
+#endif
+}
 
 int akoHipDeviceCount(void)
 {

@@ -32,6 +32,8 @@ typedef struct akoHipPlan akoHipPlan;
 
 /* Number of usable HIP devices (0 when there is none or the runtime cannot initialise). */
 int akoHipDeviceCount(void);
+/* 1 when built with AKO_BUILD_EXPERIMENTAL=1 (the routes AKO_HIP_FUSE2 / AKO_HIP_GROUP select exist), else 0 */
+int akoHipHasExperimental(void);
 
 /* Reason of the last failure on this thread ("" if none). */
 const char* akoHipLastError(void);

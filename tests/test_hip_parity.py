@@ -4,6 +4,7 @@ and the golden vectors generated from the compiled reference.  Bar: bit-exact (a
 import ctypes as C
 import os
 import random
+import hashlib
 import zlib
 
 import numpy as np
@@ -51,6 +52,8 @@ def path_mode(request):
     '-noopt' runs the exact int16-wrapping inverse alone instead of optimistic fp32 + exact fallback."""
     old = {k: os.environ.get(k) for k in ("AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_STAGED", "AKO_HIP_FUSE2", "AKO_HIP_LEAN")}
     mode = request.param
+    if mode.endswith("-fuse2") and not _has_experimental():
+        pytest.skip("experimental routes are not in this library (AKO_BUILD_EXPERIMENTAL=1 python -m ako_amd.build; AKO_LIB_OVERRIDE)")
     os.environ["AKO_HIP_PATH"] = mode.split("-")[0]
     # AKO_HIP_TAIL: 0 no in-LDS tail, 1 (default) the window-engine tail
     os.environ.pop("AKO_HIP_TAIL", None)
@@ -73,6 +76,15 @@ def path_mode(request):
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
+
+
+def _has_experimental():
+    """The routes AKO_HIP_FUSE2 / AKO_HIP_GROUP select (levels 0 + 1 in one workgroup walk, level 0 in column groups) lost their
+    measurements and are only in a library built with AKO_BUILD_EXPERIMENTAL=1 (ako_amd/libako_experimental.so): run their
+    parity tests with AKO_LIB_OVERRIDE pointing at it."""
+    L = api.lib()
+    L.akoHipHasExperimental.restype = C.c_int
+    return bool(L.akoHipHasExperimental())
 
 
 def test_device_present():
@@ -313,6 +325,8 @@ def test_fused2_levels_0_and_1_in_one_workgroup_walk(po):
     6 rows, short first / last segment) and the four borders can fall; DD13/7 and CDF5/3; CLAMP, MIRROR, ZERO; tiled
     and batched; gates and quantizers -- streams byte-for-byte against the oracle, decoded pixels bit-exact, and the
     kernel records must show that the fused kernels are what ran."""
+    if not _has_experimental():
+        pytest.skip("experimental routes are not in this library (AKO_BUILD_EXPERIMENTAL=1 python -m ako_amd.build; AKO_LIB_OVERRIDE)")
     nrng = np.random.default_rng(5150)
     cases = [(1024, 96, 0), (1408, 200, 0), (1424, 264, 0), (2816, 120, 0), (2832, 48, 0), (4096, 192, 0), (1040, 776, 0),
              (1440, 1000, 0), (2048, 1024, 512), (1536, 768, 256), (8192, 104, 0), (5648, 72, 0), (64, 64, 0), (136, 52, 0)]
@@ -365,6 +379,8 @@ def test_column_groups_at_level_0(po):
     starts at so that one group, two groups, the first / last group's border lines, strips beyond the right border,
     tiles and batches whose streams start at other phases, odd heights, every border rule and both colour paths are
     covered at test sizes -- streams byte-for-byte against the oracle, decoded pixels bit-exact."""
+    if not _has_experimental():
+        pytest.skip("experimental routes are not in this library (AKO_BUILD_EXPERIMENTAL=1 python -m ako_amd.build; AKO_LIB_OVERRIDE)")
     nrng = np.random.default_rng(777)
     cases = [(128, 64, 0), (256, 97, 0), (896, 50, 0), (1024, 96, 0), (1152, 201, 0), (2048, 136, 0), (2816, 120, 0), (4096, 77, 0),
              (8192, 40, 0), (1024, 768, 256), (1536, 512, 512), (2048, 1100, 512), (5760, 64, 0), (640, 300, 128)]
@@ -748,6 +764,13 @@ def test_config1_plane_4096_lifting_only(po):
         assert np.array_equal(st.cpu().numpy().reshape(-1), po.lift_plane(0, 0, plane))
 
 
+def _sha256(*parts):
+    h = hashlib.sha256()
+    for p in parts:
+        h.update(memoryview(np.ascontiguousarray(p)).cast("B"))
+    return h.hexdigest()
+
+
 def _checksum_case(po, exp, s, img, batch=1):
     h, w, ch = img.shape
     with api.Plan(_to_api(s), ch, w, h, batch=batch) as plan:
@@ -765,8 +788,10 @@ def _checksum_case(po, exp, s, img, batch=1):
             a = zlib.adler32(body, zlib.adler32(head)) & 0xFFFFFFFF
             assert body.size + 16 == exp["blob"]["bytes"]
             assert f"{a:08x}" == exp["blob"]["adler32"]
+            assert _sha256(head, body) == exp["blob"]["sha256"]  # (Adler-32 alone is a weak witness over half a gigabyte)
             dec = d_back[b].cpu().numpy()
             assert f"{po.adler32(dec):08x}" == exp["decoded"]["adler32"]
+            assert _sha256(dec) == exp["decoded"]["sha256"]
     return True
 
 
@@ -791,24 +816,28 @@ def test_config2_8192_full_path(po, golden_sums):
 
 
 def test_config3_batch_of_4k_images(po, golden_sums):
-    """BASELINE configs[3] on one GPU: a batch of 3840x2160 images, image i seeded 0x9E3779B9 + i."""
-    n = 4
-    imgs = np.stack([po.gen_image(0, 3840, 2160, seed=0x9E3779B9 + i) for i in range(n)])
+    """BASELINE configs[3] on one GPU: ALL 64 images of 3840x2160, image i seeded 0x9E3779B9 + i, in batches of eight on one
+    plan; stream and decoded pixels of every image against the reference's SHA-256 (tests/golden/make_golden_cfg3.py)."""
+    n, chunk = 64, 8
     s = api.settings(wavelet=0, compression=2, q=16, g=16)
-    with api.Plan(s, 4, 3840, 2160, batch=n) as plan:
-        d_img = torch.from_numpy(imgs).cuda()
-        d_str = plan.encode(d_img)
-        d_back = plan.decode(d_str)
-        plan.synchronize()
-        head = np.zeros(16, np.uint8)
-        o = po.settings(wavelet=0, color=3, compression=2)
-        assert po.lib().orcHeadWrite(4, 3840, 2160, C.byref(o), head.ctypes.data_as(C.c_void_p)) == 0
-        for i in range(n):
-            exp = golden_sums["baseline"][f"cfg3_4k_image{i}"]
-            body = d_str[i].cpu().numpy().view(np.uint8)
-            a = zlib.adler32(body, zlib.adler32(head)) & 0xFFFFFFFF
-            assert f"{a:08x}" == exp["blob"]["adler32"]
-            assert f"{po.adler32(d_back[i].cpu().numpy()):08x}" == exp["decoded"]["adler32"]
+    head = np.zeros(16, np.uint8)
+    o = po.settings(wavelet=0, color=3, compression=2)
+    assert po.lib().orcHeadWrite(4, 3840, 2160, C.byref(o), head.ctypes.data_as(C.c_void_p)) == 0
+    with api.Plan(s, 4, 3840, 2160, batch=chunk) as plan:
+        for first in range(0, n, chunk):
+            imgs = np.stack([po.gen_image(0, 3840, 2160, seed=0x9E3779B9 + i) for i in range(first, first + chunk)])
+            d_img = torch.from_numpy(imgs).cuda()
+            d_str = plan.encode(d_img)
+            d_back = plan.decode(d_str)
+            plan.synchronize()
+            for k in range(chunk):
+                exp = golden_sums["baseline"][f"cfg3_4k_image{first + k}"]
+                assert f"{po.adler32(imgs[k]):08x}" == exp["input_adler32"]
+                body = d_str[k].cpu().numpy().view(np.uint8)
+                assert body.size + 16 == exp["blob"]["bytes"]
+                assert _sha256(head, body) == exp["blob"]["sha256"], first + k
+                assert _sha256(d_back[k].cpu().numpy()) == exp["decoded"]["sha256"], first + k
+            del d_img, d_str, d_back
 
 
 @pytest.mark.parametrize("name", ["cfg4_16384_cdf53_lossless_t256", "cfg4_16384_cdf53_lossless_t512",
@@ -833,6 +862,7 @@ def test_config4_16384_lossless_round_trip(po, golden_sums, name):
         assert body.size + 16 == exp["blob"]["bytes"]
         a = zlib.adler32(body, zlib.adler32(head)) & 0xFFFFFFFF
         assert f"{a:08x}" == exp["blob"]["adler32"]
+        assert _sha256(head, body) == exp["blob"]["sha256"]
 
 
 # ---- the public ako.h entry points -------------------------------------------------------------
@@ -1126,10 +1156,19 @@ def test_api_cached_plans_die_with_their_thread(po):
     # What the HIP runtime allocates lazily and keeps (code objects, the scratch memory of every hardware queue the worker
     # threads' streams land on: tens of MB each) is not the library's to give back: one round of threads first, then the
     # baseline.
+    api.lib().akoHipThreadRelease()
+    torch.cuda.synchronize()
+    free_cold, _ = torch.cuda.mem_get_info()
     rounds(1)
     api.lib().akoHipThreadRelease()
     torch.cuda.synchronize()
     free_start, _ = torch.cuda.mem_get_info()
+    # ... but it is bounded, and the warm-up must not hide a one-time leak of the library's own: what the first round keeps after
+    # the release is the runtime's per-queue scratch ring (sized once by the largest private segment of any kernel launched on
+    # that queue: the general u8 kernels' border bodies, 84-172 bytes per lane; the lean level-0 kernels have none) plus the
+    # code objects -- 92-94 MiB per queue pair in round 3.  Eight worker threads: well under half a gigabyte.
+    assert free_cold - free_start < 512 << 20, f"the first round of threads kept {(free_cold - free_start) >> 20} MiB after release"
+
     free_a = rounds(2)    # 16 threads have come and gone
     work()                # a live caller: reaps what did not fit into the pool
     free_a = torch.cuda.mem_get_info()[0]
