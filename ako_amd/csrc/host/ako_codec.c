@@ -199,7 +199,9 @@ static akoHipPlan* pool_take(int slot, const struct plan_key* key)
 	return p;
 }
 
-/* Explicit release: the calling thread's cached plans, and every plan parked by threads that have exited. */
+static void band_pool_release(void);
+/* Explicit release: the calling thread's cached plans, every plan parked by threads that have exited, and the idle plans of
+ * the band route. */
 AKO_API void akoHipThreadRelease(void)
 {
 	struct plan_slots* sl = thread_slots(0);
@@ -220,6 +222,7 @@ AKO_API void akoHipThreadRelease(void)
 		if (parked[e] != NULL)
 			akoHipPlanDestroy(parked[e]);
 	reap_doomed();
+	band_pool_release();
 }
 
 static int plan_cache_on(void)
@@ -559,20 +562,214 @@ static __thread struct
 	int device[MAX_BANDS];
 	double seconds[MAX_BANDS];
 	size_t rows[MAX_BANDS];
+	size_t plans_created; /* by that call: 0 when every band found its plan in the pool (akoHipLastBandPlansCreated) */
 } g_last_bands;
 
-static void* band_main_timed(void* arg);
+/* ---- plans and threads of the band route outlive the call --------------------------------------------------------
+ * A band's plan holds the device buffers of a slice of a LARGE image (16384 x 16384 over eight devices: a quarter of a gigabyte
+ * of staging per band); creating and destroying it per call, on a thread created per call, cost more than the band's work
+ * (one-GPU rehearsal, round 3: 459 Mpx/s for the unsplit call, 148 cut in two).  So: a process-wide pool of band plans keyed
+ * like the per-thread slots (device, band shape, settings, direction, tuning knobs), and one persistent worker thread per
+ * band index, which keeps its HIP thread state and its spare token lists from call to call.  One split call at a time owns
+ * the workers (a second concurrent one falls back to threads of its own); AKO_HIP_PLAN_CACHE=0 restores create / destroy
+ * per call; akoHipThreadRelease() empties the pool. */
+#define BAND_POOL 32
+static struct
+{
+	akoHipPlan* plan;
+	struct plan_key key;
+	int decode, busy;
+} band_pool[BAND_POOL];
+static pthread_mutex_t band_pool_mutex = PTHREAD_MUTEX_INITIALIZER;
+static size_t band_plans_created_total = 0; /* (atomic) */
+
+struct band_worker
+{
+	pthread_t thread;
+	int alive;
+	pthread_mutex_t m;
+	pthread_cond_t cv;
+	struct band* job;
+	int done;
+};
+static struct band_worker band_workers[MAX_BANDS];
+static pthread_mutex_t band_route_mutex = PTHREAD_MUTEX_INITIALIZER;
+
+static void band_key(struct plan_key* key, const struct band* b)
+{
+	memset(key, 0, sizeof *key);
+	key->s.wavelet = b->st.wavelet, key->s.color = b->st.color, key->s.wrap = b->st.wrap, key->s.compression = b->st.compression;
+	key->s.tiles_dimension = b->st.tiles_dimension, key->s.quantization = b->st.quantization, key->s.gate = b->st.gate;
+	key->s.chroma_loss = b->st.chroma_loss, key->s.discard_non_visible = b->st.discard_non_visible;
+	key->channels = b->channels, key->w = b->w, key->h = b->rows, key->device = b->device;
+	key->tuning = akoHipTuningSignature();
+}
+
+static akoHipPlan* band_plan_take(struct band* b)
+{
+	struct plan_key key;
+	band_key(&key, b);
+	if (plan_cache_on())
+	{
+		akoHipPlan* p = NULL;
+		pthread_mutex_lock(&band_pool_mutex);
+		for (int e = 0; e < BAND_POOL && p == NULL; e++)
+			if (band_pool[e].plan != NULL && !band_pool[e].busy && band_pool[e].decode == b->decode &&
+			    memcmp(&band_pool[e].key, &key, sizeof key) == 0)
+				p = band_pool[e].plan, band_pool[e].busy = 1;
+		pthread_mutex_unlock(&band_pool_mutex);
+		if (p != NULL)
+			return p;
+	}
+	__atomic_add_fetch(&band_plans_created_total, 1, __ATOMIC_RELAXED);
+	return akoHipPlanCreate(b->device, &b->st, b->channels, b->w, b->rows, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &b->status);
+}
+
+static void band_plan_give(struct band* b, akoHipPlan* plan, int healthy)
+{
+	if (plan == NULL)
+		return;
+	akoHipPlan* drop = plan;
+	if (plan_cache_on())
+	{
+		struct plan_key key;
+		band_key(&key, b);
+		pthread_mutex_lock(&band_pool_mutex);
+		int mine = -1, empty = -1, idle = -1;
+		for (int e = 0; e < BAND_POOL; e++)
+		{
+			if (band_pool[e].plan == plan)
+				mine = e;
+			else if (band_pool[e].plan == NULL && empty < 0)
+				empty = e;
+			else if (band_pool[e].plan != NULL && !band_pool[e].busy && idle < 0)
+				idle = e;
+		}
+		if (mine >= 0) /* taken from the pool: stays, or leaves if the call failed on it */
+		{
+			if (healthy)
+				band_pool[mine].busy = 0, drop = NULL;
+			else
+				band_pool[mine].plan = NULL, band_pool[mine].busy = 0;
+		}
+		else if (healthy)
+		{
+			const int at = (empty >= 0) ? empty : idle; /* a full pool gives up an idle plan of some other shape */
+			if (at >= 0)
+			{
+				drop = band_pool[at].plan; /* NULL for an empty entry */
+				band_pool[at].plan = plan, band_pool[at].key = key, band_pool[at].decode = b->decode, band_pool[at].busy = 0;
+			}
+		}
+		pthread_mutex_unlock(&band_pool_mutex);
+	}
+	if (drop != NULL)
+		akoHipPlanDestroy(drop);
+}
+
+static void band_pool_release(void) /* akoHipThreadRelease */
+{
+	akoHipPlan* idle[BAND_POOL];
+	int n = 0;
+	pthread_mutex_lock(&band_pool_mutex);
+	for (int e = 0; e < BAND_POOL; e++)
+		if (band_pool[e].plan != NULL && !band_pool[e].busy)
+			idle[n++] = band_pool[e].plan, band_pool[e].plan = NULL;
+	pthread_mutex_unlock(&band_pool_mutex);
+	for (int e = 0; e < n; e++)
+		akoHipPlanDestroy(idle[e]);
+}
+
+/* akoHostDecodeBody() for a band of a tiled Kagari blob, with the single-device driver's parse: the tiles of a window are
+ * tokenized on worker threads and their lists merged by the same threads (tokenize_tiles, merge_window), the token lists
+ * stay with the thread for its next call (a band worker is persistent).  A band of 16384 x 8192 in 512-pixel tiles holds
+ * 512 bit-streams, 85 MB of payload: parsed tile after tile on the band's own thread it took 1.2 s of the band's 1.3 s. */
+static enum akoStatus band_decode_body(akoHipPlan* plan, enum akoCompression compression, const uint8_t* body, size_t body_bytes,
+                                       void* pixels)
+{
+	const size_t tiles = akoHipPlanTiles(plan);
+	if (compression == AKO_COMPRESSION_NONE || tiles < 2)
+		return akoHostDecodeBody(plan, compression, body, body_bytes, NULL, pixels);
+	struct akoKagariTokens tokens;
+	tokens_take(&tokens);
+	size_t n_jobs = tokenize_workers() * 8;
+	if (n_jobs > tiles)
+		n_jobs = tiles;
+	struct tile_job* jobs = calloc(n_jobs, sizeof *jobs);
+	if (jobs == NULL)
+	{
+		tokens_give(&tokens);
+		return AKO_NO_ENOUGH_MEMORY;
+	}
+	enum akoStatus status = AKO_OK;
+	const uint8_t* walk = body;
+	const uint8_t* const end = body + body_bytes;
+	for (size_t first = 0; first < tiles && status == AKO_OK;)
+	{
+		const size_t count = (tiles - first < n_jobs) ? tiles - first : n_jobs;
+		for (size_t k = 0; k < count; k++)
+		{
+			size_t o = 0, b = 0;
+			akoHipPlanTileInfo(plan, first + k, NULL, NULL, NULL, NULL, &o, &b);
+			memset(&jobs[k], 0, sizeof jobs[k]); /* payload == NULL: the chain ran off the input before this tile */
+			uint32_t blk = 0;
+			if (walk == NULL || (size_t)(end - walk) < 4)
+			{
+				walk = NULL;
+				continue;
+			}
+			memcpy(&blk, walk, 4);
+			if ((size_t)(end - walk) - 4 < blk)
+			{
+				walk = NULL;
+				continue;
+			}
+			jobs[k].payload = walk + 4, jobs[k].block = blk;
+			jobs[k].values = b / 2, jobs[k].out_base = o / 2;
+			walk += (size_t)blk + 4;
+		}
+		tokenize_tiles(jobs, count);
+		merge_window(jobs, count, &tokens, tiles - first - count);
+		for (size_t k = 0; k < count; k++)
+		{
+			struct tile_job* j = &jobs[k];
+			if (status == AKO_OK && (j->payload == NULL || j->used == 0 || j->used != j->block)) /* compression.c:69-70 */
+				status = AKO_BROKEN_INPUT;
+			if (status == AKO_OK && !j->merged)
+			{
+				const size_t base = tokens.n_literals;
+				if (base + j->tok.n_literals > 0xFFFFFFF0ull || !akoHostKagariTokensAppend(&tokens, &j->tok, (uint32_t)base))
+					status = AKO_NO_ENOUGH_MEMORY;
+			}
+			if (!j->merged)
+				akoHostKagariTokensFree(&j->tok);
+		}
+		first += count;
+	}
+	free(jobs);
+	if (status == AKO_OK)
+	{
+		int rc = akoHipKagariExpand(plan, tokens.literals, tokens.n_literals, (const struct akoHipKagariRun*)tokens.runs, tokens.n_runs, NULL, 0);
+		if (rc == 0)
+			rc = akoHipDecodeDownload(plan, pixels);
+		status = (enum akoStatus)rc;
+	}
+	tokens_give(&tokens);
+	return status;
+}
+
 static void* band_main(void* arg)
 {
 	struct band* b = arg;
-	if (b->plan == NULL)
-		b->plan = akoHipPlanCreate(b->device, &b->st, b->channels, b->w, b->rows, 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &b->status);
-	if (b->plan == NULL)
+	akoHipPlan* plan = (b->plan != NULL) ? b->plan : band_plan_take(b); /* (the decoder of uncompressed blobs takes them beforehand) */
+	b->plan = NULL;
+	if (plan == NULL)
 		return NULL;
 	if (b->decode)
-		b->status = akoHostDecodeBody(b->plan, b->st.compression, b->body_in, b->body_in_bytes, NULL, b->pixels_out);
+		b->status = band_decode_body(plan, b->st.compression, b->body_in, b->body_in_bytes, b->pixels_out);
 	else
-		b->status = akoHostEncodeBody(b->plan, b->st.compression, b->pixels_in, 0, &b->body_out, &b->body_out_bytes);
+		b->status = akoHostEncodeBody(plan, b->st.compression, b->pixels_in, 0, &b->body_out, &b->body_out_bytes);
+	band_plan_give(b, plan, b->status == AKO_OK);
 	return NULL;
 }
 
@@ -587,31 +784,91 @@ static void* band_main_timed(void* arg)
 	return NULL;
 }
 
+static void* band_worker_main(void* arg)
+{
+	struct band_worker* w = arg;
+	for (;;)
+	{
+		pthread_mutex_lock(&w->m);
+		while (w->job == NULL)
+			pthread_cond_wait(&w->cv, &w->m);
+		struct band* b = w->job;
+		pthread_mutex_unlock(&w->m);
+		band_main_timed(b);
+		pthread_mutex_lock(&w->m);
+		w->job = NULL, w->done = 1;
+		pthread_cond_broadcast(&w->cv);
+		pthread_mutex_unlock(&w->m);
+	}
+	return NULL;
+}
+
+/* hands band b to persistent worker k (created on first use; the caller holds band_route_mutex); 0 if that is not possible */
+static int band_worker_post(size_t k, struct band* b)
+{
+	struct band_worker* w = &band_workers[k];
+	if (!w->alive)
+	{
+		pthread_attr_t at;
+		if (pthread_mutex_init(&w->m, NULL) != 0 || pthread_cond_init(&w->cv, NULL) != 0 || pthread_attr_init(&at) != 0)
+			return 0;
+		pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+		w->job = NULL, w->done = 0;
+		const int rc = pthread_create(&w->thread, &at, band_worker_main, w);
+		pthread_attr_destroy(&at);
+		if (rc != 0)
+			return 0;
+		w->alive = 1;
+	}
+	pthread_mutex_lock(&w->m);
+	w->done = 0, w->job = b;
+	pthread_cond_broadcast(&w->cv);
+	pthread_mutex_unlock(&w->m);
+	return 1;
+}
+static void band_worker_wait(size_t k)
+{
+	struct band_worker* w = &band_workers[k];
+	pthread_mutex_lock(&w->m);
+	while (!w->done)
+		pthread_cond_wait(&w->cv, &w->m);
+	pthread_mutex_unlock(&w->m);
+}
+
 /* bands[0 .. n) filled in by the caller; runs them (band 0 on the calling thread) and returns the first failure */
 static enum akoStatus run_bands(struct band* bands, size_t n)
 {
+	const size_t created_before = __atomic_load_n(&band_plans_created_total, __ATOMIC_RELAXED);
+	/* started: 2 = a persistent worker has it, 1 = a thread of this call, 0 = nobody yet (run here afterwards) */
+	const int pooled = plan_cache_on() && pthread_mutex_trylock(&band_route_mutex) == 0;
 	for (size_t k = 1; k < n; k++)
-		bands[k].started = (pthread_create(&bands[k].thread, NULL, band_main_timed, &bands[k]) == 0);
+	{
+		if (pooled && band_worker_post(k, &bands[k]))
+			bands[k].started = 2;
+		else
+			bands[k].started = (pthread_create(&bands[k].thread, NULL, band_main_timed, &bands[k]) == 0);
+	}
 	band_main_timed(&bands[0]);
 	for (size_t k = 1; k < n; k++)
 	{
-		if (bands[k].started)
+		if (bands[k].started == 2)
+			band_worker_wait(k);
+		else if (bands[k].started)
 			pthread_join(bands[k].thread, NULL);
 		else
 			band_main_timed(&bands[k]);
 	}
+	if (pooled)
+		pthread_mutex_unlock(&band_route_mutex);
 	g_last_bands.n = n < MAX_BANDS ? n : MAX_BANDS;
 	for (size_t k = 0; k < g_last_bands.n; k++)
 		g_last_bands.device[k] = bands[k].device, g_last_bands.seconds[k] = bands[k].seconds, g_last_bands.rows[k] = bands[k].rows;
+	/* (exact unless another thread split a call at the same time: it is a diagnostic) */
+	g_last_bands.plans_created = __atomic_load_n(&band_plans_created_total, __ATOMIC_RELAXED) - created_before;
 	enum akoStatus st = AKO_OK;
 	for (size_t k = 0; k < n; k++)
-	{
-		if (bands[k].plan != NULL)
-			akoHipPlanDestroy(bands[k].plan);
-		bands[k].plan = NULL;
 		if (st == AKO_OK && bands[k].status != AKO_OK)
 			st = bands[k].status;
-	}
 	return st;
 }
 
@@ -1020,6 +1277,14 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 				status = AKO_NO_ENOUGH_MEMORY;
 				goto failure;
 			}
+			{
+				/* a fresh buffer that the bands' downloads touch first: 2 MB faults instead of 4 KB ones where the system allows */
+				const size_t image_bytes = image_w * image_h * channels;
+				const uintptr_t lo = ((uintptr_t)image + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+				const uintptr_t hi = ((uintptr_t)image + image_bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+				if (image_bytes >= ((size_t)16 << 20) && hi > lo)
+					(void)madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+			}
 			/* where every band's body starts: fixed stream sizes without compression, the chain of block sizes with */
 			const uint8_t* at = (const uint8_t*)input + sizeof(struct akoHead);
 			const uint8_t* const stop = (const uint8_t*)input + input_size;
@@ -1032,9 +1297,12 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 				b->body_in = at;
 				if (st.compression == AKO_COMPRESSION_NONE)
 				{
-					/* plans are created here, one after the other, for the sizes of their streams */
-					if ((b->plan = akoHipPlanCreate(b->device, &st, channels, image_w, rows[k], 1, NULL, AKO_HIP_PLAN_OWN_STREAM, &status)) == NULL)
+					/* plans are taken (from the band pool, or created) here, one after the other, for the sizes of their streams */
+					if ((b->plan = band_plan_take(b)) == NULL)
+					{
+						status = (b->status != AKO_OK) ? b->status : AKO_ERROR;
 						break;
+					}
 					const size_t need = akoHipPlanStreamBytes(b->plan);
 					if ((size_t)(stop - at) < need)
 						status = AKO_BROKEN_INPUT;
@@ -1067,8 +1335,7 @@ AKO_API uint8_t* akoDecodeExt(const struct akoCallbacks* c, size_t input_size, c
 				status = run_bands(bands, nb);
 			else
 				for (size_t k = 0; k < nb; k++)
-					if (bands[k].plan != NULL)
-						akoHipPlanDestroy(bands[k].plan);
+					band_plan_give(&bands[k], bands[k].plan, 1);
 			if (status != AKO_OK)
 			{
 				if (status != AKO_BROKEN_INPUT)
@@ -1578,6 +1845,12 @@ failure:
 
 /* The bands of the calling thread's last akoEncodeExt / akoDecodeExt that was split over devices (AKO_HIP_DEVICES): device,
  * seconds (plan, transform, entropy stage, copies) and image rows of each, in band order; returns their number. */
+/* Plans the calling thread's last split call had to CREATE (0: every band found its plan in the pool). */
+AKO_API size_t akoHipLastBandPlansCreated(void)
+{
+	return g_last_bands.n ? g_last_bands.plans_created : 0;
+}
+
 AKO_API size_t akoHipLastBands(int* devices, double* seconds, size_t* rows, size_t cap)
 {
 	const size_t n = g_last_bands.n < cap ? g_last_bands.n : cap;

@@ -137,9 +137,11 @@ struct bit_source
 	const uint8_t* at;
 	const uint8_t* end;
 	const uint8_t* base;
-	int saw_long; /* codes of more than 31 bits that came by (no int16 value has one): damaged input.  Whether such a code fits
-	               * what is 'held' depends on the refill history, which a parser that joined the stream halfway does not
-	               * share with the sequential reader -- the parallel tokenizer hands such blocks back */
+	int saw_long; /* codes of more than 31 bits that came by: damaged input.  No value the ENCODER can write has one: the longest,
+	               * 31 bits, belong to zigzag + 1 = 32768 .. 65535; -32768 would need 65536, which the reference's uint16_t code
+	               * word (kagari.c:172-178) cannot hold -- it has no code at all, and a block with it fails to encode.  Whether
+	               * an over-long code fits what is 'held' depends on the refill history, which a parser that joined the
+	               * stream halfway does not share with the sequential reader -- the parallel tokenizer hands such blocks back */
 };
 
 /* Next gamma code, low 16 bits (kagari.c keeps it in a uint16_t, so an over-long code simply wraps).

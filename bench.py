@@ -386,9 +386,13 @@ def host_route(args) -> int:
         L.akoHipLastBands.restype = C.c_size_t
         L.akoHipLastBands.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_size_t), C.c_size_t]
 
+        L.akoHipLastBandPlansCreated.restype = C.c_size_t
+        plans_created = {"encode": [], "decode": []}  # per timed call: 0 once the band route's plan pool is warm
+
         def bands(tag):
             dv, sec, rows = (C.c_int * 16)(), (C.c_double * 16)(), (C.c_size_t * 16)()
             n = L.akoHipLastBands(dv, sec, rows, 16)
+            plans_created[tag].append(int(L.akoHipLastBandPlansCreated()))
             for k in range(n):
                 e = per_dev.setdefault(dv[k], {"bands": 0, "rows": 0, "encode_busy_s": 0.0, "decode_busy_s": 0.0})
                 e[tag + "_busy_s"] += sec[k]
@@ -416,7 +420,8 @@ def host_route(args) -> int:
             dec_s += t2 - t1
         px = float(w * h) * steps
         workload = f"configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles {td}, host pixels -> .ako (Kagari) -> host pixels, bands of tile rows over the devices"
-        extra = {"bands": n_bands, "encode_Mpx_s": round(px / enc_s / 1e6, 1), "decode_Mpx_s": round(px / dec_s / 1e6, 1), "blob_bytes": int(blob.size)}
+        extra = {"bands": n_bands, "encode_Mpx_s": round(px / enc_s / 1e6, 1), "decode_Mpx_s": round(px / dec_s / 1e6, 1), "blob_bytes": int(blob.size),
+                 "band_plans_created_per_timed_call": plans_created}
         elapsed = enc_s + dec_s
         for e in per_dev.values():  # per step
             e["bands"] //= steps

@@ -229,6 +229,9 @@ int akoHipHostIsPinned(const void* p); /* 1: page-locked memory the HIP runtime 
 /* The bands of the calling thread's last akoEncodeExt / akoDecodeExt that was split over devices (AKO_HIP_DEVICES): device,
  * seconds and image rows of each, in band order (at most `cap` written); returns their number (0: the call was not split). */
 size_t akoHipLastBands(int* devices, double* seconds, size_t* rows, size_t cap);
+/* ... and how many band plans that call had to create: the band route keeps its plans (per device, band shape, settings and
+ * direction) and its worker threads from call to call, so a repeated call reports 0 (AKO_HIP_PLAN_CACHE=0: one per band). */
+size_t akoHipLastBandPlansCreated(void);
 
 /* measurement aid: read + write GB/s of a tuned device-to-device copy of `bytes` on the current device (two temporary
  * buffers of that size); the practical memory rate bench.py reports beside the 8 TB/s spec peak.  0 on failure. */
