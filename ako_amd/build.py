@@ -23,6 +23,7 @@ HIP_SOURCES = {
                      "ako_requant.hip.h", "ako_fused.h", "ako_u8.h"],
     "ako_u8_rgba.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8_lean.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
     "ako_u8_rgb.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8_lean.hip.h", "ako_u8.h", "ako_u8_tu.hip.h"],
+    "ako_u8_gray.hip": ["ako_kernels.hip.h", "ako_stream.hip.h", "ako_u8_lean.hip.h", "ako_u8_gray.hip.h", "ako_u8.h"],
     "ako_copy.hip": [],
 }
 # The routes that lost their measurements (levels 0 + 1 in one workgroup walk, AKO_HIP_FUSE2; level 0 in column groups with

@@ -462,6 +462,39 @@ bool rgb_native(const akoHipPlan* pl)
 	       (pl->s.tiles_dimension == 0 || (pl->s.tiles_dimension % 4) == 0);
 }
 
+// One- and two-channel u8 images on the native gray kernels (ako_u8_gray.hip.h) instead of the staged route?  The kernels are
+// written in the lean style and take the lean kernels' geometry: DD13/7 or CDF5/3 at level 0, any border rule but MIRROR, a
+// level width that is a multiple of four, ordinary strips (no wide strip, no row strips over tiles).  AKO_HIP_STAGED=2 and
+// AKO_HIP_LEAN=0 keep such images staged.
+uint32_t row_strips(const akoHipPlan* pl, const Group& g, const LevelGeom& L, bool u8);
+bool gray_native(const akoHipPlan* pl, const Group& g)
+{
+	if ((pl->flags & AKO_HIP_PLAN_PLANES_I16) || (pl->channels != 1 && pl->channels != 2) || g.levels.empty())
+		return false;
+	if (!pl->tune.interior || pl->tune.staged == 2 || pl->s.wrap == AKO_WRAP_MIRROR)
+		return false;
+	const LevelGeom& L = g.levels[0];
+	if ((L.kind != K_DD137 && L.kind != K_CDF53) || (L.cw & 3u) != 0 || L.cw != 2 * L.tw)
+		return false;
+	if (L.tw > (uint32_t)SNET && L.tw <= 128 && pl->tune.wide)
+		return false;  // (one wide strip: general kernels only)
+	return row_strips(pl, g, L, true) == 0;
+}
+bool gray_native_any(const akoHipPlan* pl)
+{
+	for (const Group& g : pl->groups)
+		if (gray_native(pl, g))
+			return true;
+	return false;
+}
+
+bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8);
+// ... and level 0 of that group is one the streaming kernels take at all
+bool gray_level0(const akoHipPlan* pl, const Group& g)
+{
+	return gray_native(pl, g) && stream_eligible(pl, g.levels[0], false);
+}
+
 bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 {
 	const int mode = path_mode(pl);
@@ -470,7 +503,7 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 	if (!stream_width_ok(pl, L) || L.th < 2)
 		return false;
 	if (u8 && !(pl->channels == 4 || rgb_native(pl)))
-		return false;
+		return false;  // (one / two channels: gray_level0() below)
 	// the forward streaming kernels address a tile's stream and the LL scratch planes with 32-bit byte
 	// offsets (raw buffer stores): tiles of 4 GiB and more stay on the window engine
 	for (const Group& g : pl->groups)
@@ -947,6 +980,8 @@ bool staged_level0(const akoHipPlan* pl, const Group& g)
 		return false;
 	if (rgb_native(pl) && stream_eligible(pl, g.levels[0], true))
 		return false;  // the u8 kernels take RGB themselves
+	if (gray_level0(pl, g))
+		return false;  // ... and the gray kernels one / two channels
 	if (pl->s.wavelet == AKO_WAVELET_NONE || path_mode(pl) == PATH_GENERIC)
 		return false;
 	if (!pl->tune.staged)
@@ -1062,12 +1097,15 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				P.dst_inst_stride = P.dst_plane_stride * pl->channels;
 			}
 
-			const bool streaming = stream_eligible(pl, L, u8);
+			const bool gray = u8 && pl->channels <= 2 && gray_level0(pl, g);  // one / two channels on the native gray kernels
+			const bool streaming = gray || stream_eligible(pl, L, u8);
 			Launch LA{pl, 0};
 			char name[48];
 			if (streaming)
 			{
-				if (u8)
+				if (gray)
+					P.planes_per_wg = (uint32_t)pl->channels, P.plane_groups = 1;  // one wave per strip carries every plane
+				else if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip
 				const bool grouped = u8 && grouped0;
 				// small tiles side by side in one wave: the tile instances of a launch then count in packs
@@ -1081,7 +1119,7 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 				const StreamGeom G = grouped ? stream_geometry(pl, L, (uint64_t)GRP_WAVES * insts, u8, false, group_count(L.tw))
 				                             : stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, false, 0, pack, rowt);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * pinsts;
-				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.fwd_pairs : (uint32_t)(THREADS / 64);
+				const uint32_t waves_per_block = gray ? 4u : (u8 ? 2u * (uint32_t)pl->tune.fwd_pairs : (uint32_t)(THREADS / 64));
 				const uint64_t blocks = grouped ? (uint64_t)G.strips * G.segs * insts : (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
 					return rc;
@@ -1099,7 +1137,9 @@ int run_encode(akoHipPlan* pl, const void* d_images, void* d_streams)
 					hipLaunchKernelGGL(k_forward_stream_i16_memonly<>, dim3((uint32_t)blocks), dim3(THREADS), 0, pl->stream, P, G);
 				else
 #endif
-				if (grouped)
+				if (gray)
+					akoLaunchForwardU8_gray(L.kind, (int)pl->channels, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
+				else if (grouped)
 					akoLaunchForwardGroupU8_rgba(L.kind, P, G, (uint32_t)blocks, pl->stream);
 				else if (u8 && pl->channels == 3)
 					akoLaunchForwardU8_rgb(L.kind, lean_u8_level(pl, P, G, L.kind, true), P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
@@ -1235,12 +1275,15 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				P.dst_inst_stride = P.dst_plane_stride * pl->channels;
 			}
 
-			const bool streaming = stream_eligible(pl, L, u8);
+			const bool gray = u8 && pl->channels <= 2 && gray_level0(pl, g);  // one / two channels on the native gray kernels
+			const bool streaming = gray || stream_eligible(pl, L, u8);
 			Launch LA{pl, 1};
 			char name[48];
 			if (streaming)
 			{
-				if (u8)
+				if (gray)
+					P.planes_per_wg = (uint32_t)pl->channels, P.plane_groups = 1;  // one wave per strip carries every plane
+				else if (u8)
 					P.planes_per_wg = 2, P.plane_groups = 2;  // a pair of waves per RGBA strip = one workgroup
 				const uint32_t pack = (l == 0) ? 0u : tile_pack(pl, g, L, u8);
 				const uint32_t rowt = (l != 0 || f2inv) ? 0u : row_strips(pl, g, L, u8);
@@ -1249,7 +1292,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				                               : insts;
 				const StreamGeom G = stream_geometry(pl, L, (uint64_t)P.plane_groups * pinsts, u8, true, 0, pack, rowt);
 				const uint64_t units = (uint64_t)G.strips * G.segs * P.plane_groups * pinsts;
-				const uint32_t waves_per_block = u8 ? 2u * (uint32_t)pl->tune.inv_pairs : (uint32_t)(THREADS / 64);
+				const uint32_t waves_per_block = gray ? 4u : (u8 ? 2u * (uint32_t)pl->tune.inv_pairs : (uint32_t)(THREADS / 64));
 				const int deep = deep_prefetch(pl, G, u8);
 				const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
 				if (int rc = check_blocks(blocks))
@@ -1259,7 +1302,7 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				const bool behind_fused = f2inv && l <= 1;  // exact kernel only, behind the two-level launch
 				if (behind_fused)
 					P.ovf_flag = f2_flag, P.ovf_gen = f2_gen;
-				const bool optimistic = u8 && pl->tune.opt;
+				const bool optimistic = u8 && !gray && pl->tune.opt;  // (the gray kernel IS the exact pipeline: one launch)
 				if (optimistic && !behind_fused)
 				{
 					const size_t slot = (gi * 8 + l) % 64;
@@ -1289,7 +1332,9 @@ int run_decode(akoHipPlan* pl, const void* d_streams, void* d_images)
 				}
 				if (int rc = LA.begin())
 					return rc;
-				if (u8)
+				if (gray)
+					akoLaunchInverseU8_gray(L.kind, (int)pl->channels, P, G, (uint32_t)blocks, 64 * waves_per_block, pl->stream);
+				else if (u8)
 					launch_inverse_u8(pl, false, L.kind, P, G, (uint32_t)blocks);
 				else if (deep == DEEP_SLOTS_SHORT)
 					launch_inverse_stream<1, false, false, DEEP_SLOTS_SHORT>(L.kind, P, G, (uint32_t)blocks, pl->stream);

@@ -15,4 +15,9 @@ void akoLaunchForwardGroupU8_rgba(int kind, const LevelParams& P, const StreamGe
 void akoLaunchInverseU8_rgba(int kind, bool opt, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
 void akoLaunchInverseU8_rgb(int kind, bool opt, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t pairs, hipStream_t st);
 
+// one- and two-channel images (ako_u8_gray.hip.h): one wave per strip carrying all planes; the inverse is the exact integer
+// pipeline (no optimistic launch in front of it); the caller has checked gray_native_level()
+void akoLaunchForwardU8_gray(int kind, int channels, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
+void akoLaunchInverseU8_gray(int kind, int channels, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st);
+
 }  // namespace ako

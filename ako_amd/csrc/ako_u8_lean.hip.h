@@ -173,6 +173,7 @@ template <int KIND, bool HB, typename V>
 __device__ __forceinline__ void hlift_inverse_bf(V L0, V L1, V H0, V H1, const HEdgeBF& e, V& E0, V& O0, V& E1, V& O1)
 {
 	static_assert(KIND != K_HAAR, "lifting wavelets");
+	constexpr bool NRW = std::is_same<V, int>::value;  // the integer pipe wraps to int16 after every step like the reference
 	V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
 	V hL0 = (V)0, hR0 = (V)0;
 	if constexpr (KIND == K_DD137)
@@ -184,8 +185,8 @@ __device__ __forceinline__ void hlift_inverse_bf(V L0, V L1, V H0, V H1, const H
 		if constexpr (KIND == K_DD137)
 			hL0 = e.first ? lo : hL0, hR0 = e.last ? hi : hR0;
 	}
-	E0 = lift_add<false>(L0, sum_u<KIND, -1>(hL0, hL1, H0, H1), shift_u<KIND>());
-	E1 = lift_add<false>(L1, sum_u<KIND, -1>(hL1, H0, H1, hR0), shift_u<KIND>());
+	E0 = lift_add<NRW>(L0, sum_u<KIND, -1>(hL0, hL1, H0, H1), shift_u<KIND>());
+	E1 = lift_add<NRW>(L1, sum_u<KIND, -1>(hL1, H0, H1, hR0), shift_u<KIND>());
 	V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
 	V eL = (V)0, eR1 = (V)0;
 	if constexpr (KIND == K_DD137)
@@ -197,8 +198,8 @@ __device__ __forceinline__ void hlift_inverse_bf(V L0, V L1, V H0, V H1, const H
 		if constexpr (KIND == K_DD137)
 			eL = e.first ? lo : eL, eR1 = e.last ? hi : eR1;
 	}
-	O0 = lift_add<false>(H0, sum_p<KIND, -1>(eL, E0, E1, eR0), shift_p<KIND>());
-	O1 = lift_add<false>(H1, sum_p<KIND, -1>(E0, E1, eR0, eR1), shift_p<KIND>());
+	O0 = lift_add<NRW>(H0, sum_p<KIND, -1>(eL, E0, E1, eR0), shift_p<KIND>());
+	O1 = lift_add<NRW>(H1, sum_p<KIND, -1>(E0, E1, eR0, eR1), shift_p<KIND>());
 }
 template <int KIND, bool HB, typename V>
 __device__ __forceinline__ void hlift_forward_bf(V E0, V O0, V E1, V O1, const HEdgeBF& e, V& L0, V& L1, V& H0, V& H1)
@@ -279,29 +280,29 @@ __device__ __forceinline__ void vstep_forward_bf(VFwd<float>& s, float E, float 
 	hp_out = hC;
 	eA = E, oA = O, hA = H;
 }
-template <int KIND, bool VEDGE, int K>
-__device__ __forceinline__ void vstep_inverse_bf(VInv<float>& s, float LP, float HP, int v, const VEdgeBF& ve, int T, float& even_out,
-                                                 float& odd_out)
+template <int KIND, bool VEDGE, int K, typename V>
+__device__ __forceinline__ void vstep_inverse_bf(VInv<V>& s, V LP, V HP, int v, const VEdgeBF& ve, int T, V& even_out, V& odd_out)
 {
-	float& hA = s.h[K % 3];        // HP[v-3]  (overwritten by HP[v])
-	float& hB = s.h[(K + 1) % 3];  // HP[v-2]
-	float& hC = s.h[(K + 2) % 3];  // HP[v-1]
-	float& eA = s.e[K % 3];        // E[v-4]   (overwritten by E[v-1])
-	float& eB = s.e[(K + 1) % 3];  // E[v-3]
-	float& eC = s.e[(K + 2) % 3];  // E[v-2]
-	float Ev = lift_add<false>(s.l, sum_u<KIND, -1>(hA, hB, hC, HP), shift_u<KIND>());
+	constexpr bool NRW = std::is_same<V, int>::value;
+	V& hA = s.h[K % 3];        // HP[v-3]  (overwritten by HP[v])
+	V& hB = s.h[(K + 1) % 3];  // HP[v-2]
+	V& hC = s.h[(K + 2) % 3];  // HP[v-1]
+	V& eA = s.e[K % 3];        // E[v-4]   (overwritten by E[v-1])
+	V& eB = s.e[(K + 1) % 3];  // E[v-3]
+	V& eC = s.e[(K + 2) % 3];  // E[v-2]
+	V Ev = lift_add<NRW>(s.l, sum_u<KIND, -1>(hA, hB, hC, HP), shift_u<KIND>());
 	if constexpr (VEDGE)
 	{
 		const int re = v - 1, ro = v - 3;
 		const bool beyond = ve.patch && (re >= T), before = ve.zero && (re < 0), first = ve.patch && (ro == 0);
-		const float edge = ve.zero ? 0.0f : eC;  // E[T] := E[T-1]
+		const V edge = ve.zero ? (V)0 : eC;  // E[T] := E[T-1]
 		Ev = beyond ? edge : Ev;
-		Ev = before ? 0.0f : Ev;
-		const float lead = ve.zero ? 0.0f : eB;  // E[-1] := E[0]
+		Ev = before ? (V)0 : Ev;
+		const V lead = ve.zero ? (V)0 : eB;  // E[-1] := E[0]
 		eA = first ? lead : eA;
 	}
 	even_out = eB;
-	odd_out = lift_add<false>(hA, sum_p<KIND, -1>(eA, eB, eC, Ev), shift_p<KIND>());
+	odd_out = lift_add<NRW>(hA, sum_p<KIND, -1>(eA, eB, eC, Ev), shift_p<KIND>());
 	hA = HP, s.l = LP, eA = Ev;
 }
 
@@ -416,7 +417,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 					lpv[k] = zero_row ? 0.0f : lpv[k], hpv[k] = zero_row ? 0.0f : hpv[k];
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				vstep_inverse_bf<KIND, VEDGE, K>(st[p][k], lpv[k], hpv[k], v, ve, Tr, ev[p][k], od[p][k]);
+				vstep_inverse_bf<KIND, VEDGE, K, float>(st[p][k], lpv[k], hpv[k], v, ve, Tr, ev[p][k], od[p][k]);
 		}
 	};
 

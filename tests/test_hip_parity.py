@@ -571,6 +571,61 @@ def test_rgb_images_take_the_u8_kernels(po):
                 assert np.array_equal(back, od), tag
 
 
+def test_gray_and_gray_alpha_images_take_native_u8_kernels(po):
+    """One- and two-channel u8 images run level 0 on the native gray kernels (ako_u8_gray.hip.h: one wave per strip carrying
+    every plane, 4- / 8-byte pixel loads and stores, the exact integer pipeline on the way back) instead of being staged through
+    a planar int16 image (reference: library/format.c:30-84 takes any channel count in one pass, no colour transform below
+    three channels, the discard rule for two).  Streams and pixels against the oracle -- DD13/7 and CDF5/3, CLAMP / REPEAT /
+    ZERO, widths with strips at both borders and one strip only, segments with top / bottom borders, tiles, discard, lossless
+    and lossy, full-range (adversarial) streams on the way back; MIRROR, Haar, widths that are not multiples of four and
+    AKO_HIP_STAGED=2 keep the staged route."""
+    nrng = np.random.default_rng(4242)
+    cases = [(1, 256, 64, 0), (2, 256, 64, 0), (1, 1000, 300, 0), (2, 1364, 120, 0), (1, 2048, 96, 0), (2, 4096, 64, 0),
+             (1, 1024, 512, 256), (2, 640, 480, 128), (1, 512, 2048, 0), (2, 1002, 120, 0), (1, 777, 131, 0)]
+    for (ch, w, h, tiles) in cases:
+        for wavelet in (0, 1, 2):
+            for staged in (1, 2):
+                wrap = int(nrng.integers(0, 4))
+                q = int(nrng.choice([0, 1, 16, 40]))
+                g = int(nrng.choice([0, 0, 16]))
+                discard = int(nrng.integers(0, 2))
+                img = nrng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+                if ch == 2:
+                    img[nrng.random((h, w)) < 0.2, 1] = 0  # transparent pixels for the discard rule
+                s = po.settings(wavelet=wavelet, wrap=wrap, compression=2, q=q, g=g, tiles=tiles, discard=discard)
+                ob, st = po.encode_image(s, img)
+                assert st == 0
+                od, _, _ = po.decode_image(ob)
+                junk = ob.copy()
+                junk[16:] = nrng.integers(0, 256, junk.size - 16, dtype=np.uint8)
+                od2, _, st2 = po.decode_image(junk)
+                s.color = po.effective_color(s)
+                with _with_env({"AKO_HIP_PATH": "stream", "AKO_HIP_STAGED": staged}):
+                    with api.Plan(_to_api(s), ch, w, h) as plan:
+                        plan.set_profiling(True)
+                        d_streams = plan.encode(torch.from_numpy(np.ascontiguousarray(img)[None]).cuda())
+                        d_back = plan.decode(d_streams)
+                        plan.synchronize()
+                        names = [r["name"] for r in plan.kernel_records(False)] + [r["name"] for r in plan.kernel_records(True)]
+                        body = d_streams.cpu().numpy().reshape(-1).view(np.uint8)
+                        back = d_back.cpu().numpy().reshape(h, w, ch)
+                        back2 = None
+                        if st2 == 0 and od2 is not None:
+                            d_junk = torch.from_numpy(junk[16:].view(np.int16).copy()).cuda().reshape(d_streams.shape)
+                            back2 = plan.decode(d_junk).cpu().numpy().reshape(h, w, ch)
+                tag = (ch, w, h, tiles, wavelet, wrap, q, g, discard, staged)
+                tw = w if tiles == 0 else min(tiles, w)  # (the interior tile group decides)
+                native = staged == 1 and wavelet != 2 and wrap != 1 and tw % 4 == 0 and not (240 < tw <= 256) and tiles == 0
+                if tiles == 0:
+                    assert any(n.startswith(("fwd_stream_", "inv_stream_")) and n.endswith("_u8") for n in names) == native, (tag, names)
+                    if native:
+                        assert not any(n in ("u8_to_planes", "planes_to_u8") for n in names), (tag, names)
+                assert np.array_equal(body, ob[16:]), tag
+                assert np.array_equal(back, od), tag
+                if back2 is not None:
+                    assert np.array_equal(back2, od2), ("adversarial", tag)
+
+
 def test_workgroup_shapes_and_lockstep_knobs(po):
     """AKO_HIP_LOCKSTEP (barrier every six slots, strip-major int16 units) and the number of strip pairs per workgroup
     of the u8 kernels only change which waves share a workgroup and when they wait for each other: every combination
