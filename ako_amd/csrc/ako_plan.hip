@@ -619,6 +619,8 @@ StreamGeom stream_geometry(const akoHipPlan* pl, const LevelGeom& L, uint64_t wa
 	G.edge_rows = 0;
 	// u8 kernels (128 VGPRs, the top / bottom border bodies spill): short segments at the two borders, see StreamGeom
 	constexpr uint32_t EDGE_ROWS = 12;
+	// (tried for the big int16 levels too, round 4: no gain -- level 1 of the 8192 x 8192 image 86.6-87.6 us with, 85.0-85.2
+	// without; profiles/r4_lean_ab.txt)
 	if (u8 && pl->tune.seg_rows == 0 && seg_rows > EDGE_ROWS && L.th >= 3 * EDGE_ROWS + seg_rows)
 	{
 		G.edge_rows = EDGE_ROWS;

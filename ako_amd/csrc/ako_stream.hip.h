@@ -654,6 +654,17 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	// (REPEAT needs real values from the other end, and a single out-of-range lane could not compute them:
 	// its own far taps would lie beyond the wave)
 	lc.he.nh_right = wide && (Tc == 128 || wrap == W_REPEAT);
+	// Round 4: an ordinary strip at a tile border takes the border rule the way a wide strip does -- the taps of the first /
+	// last lane INSIDE the tile are substituted (border_values), the lanes beyond it compute garbage that nobody reads (a
+	// DD13/7 tap reaches one lane) -- instead of patching those lanes per sequence with v_readlane + selects behind a branch
+	// per side (fix_halo_lanes): that made a border strip 2.4-3 x as expensive as an interior one, and its waves the tail of
+	// every launch (profiles/r4_border_rule_cost.txt).  Even numbers of coefficient columns without a phantom sample only:
+	// the odd geometries move values between the slots of the border lanes and keep the old scheme.
+	if (!wide && wrap != W_REPEAT && (W & 3) == 0)
+	{
+		lc.he.nh_left = lc.he.left, lc.he.nh_right = lc.he.right;
+		lc.he.left = lc.he.right = false;
+	}
 	lc.he.oob_l = lc.c0 < 0;
 	lc.he.oob_r = lc.c0 >= Tc;
 	lc.he.lane_first = wide ? 0 : SORG / 2;
@@ -1683,6 +1694,8 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 		}
 		for (int base = 0; base < n_slots; base += 6)
 		{
+			if constexpr (!U8 && KIND == K_DD137 && !NARROW && !MEMONLY)  // (scripts/isa_lint.py finds the loop by this comment)
+				asm volatile("; AKO_LOOP fwd_i16_general_h%0_v%1" ::"n"((int)HEDGE), "n"((int)VEDGE));
 			if (G.lockstep & 1)
 				__builtin_amdgcn_s_barrier();
 			static_for<6>([&](auto kc) {
@@ -2331,6 +2344,8 @@ __device__ __forceinline__ void inverse_stream_body(const LevelParams& P, const 
 		{
 			if constexpr (U8 && OPT && KIND == K_DD137 && CH == 4 && !MEMONLY)  // (scripts/isa_lint.py finds the loop by this comment)
 				asm volatile("; AKO_LOOP inv_u8_general_h%0_v%1" ::"n"((int)HEDGE), "n"((int)VEDGE));
+			if constexpr (!U8 && KIND == K_DD137 && !MEMONLY)
+				asm volatile("; AKO_LOOP inv_i16_general_h%0_v%1" ::"n"((int)HEDGE), "n"((int)VEDGE));
 			if constexpr (!U8)  // (the u8 pairs already meet at the barriers of their LDS exchange, every slot)
 			{
 				if (G.lockstep & 1)

@@ -155,7 +155,7 @@ struct HEdgeBF
 __device__ __forceinline__ HEdgeBF hedge_bf(const HEdge& he)
 {
 	HEdgeBF e;
-	e.first = he.left && he.first, e.last = he.right && he.last;
+	e.first = (he.left || he.nh_left) && he.first, e.last = (he.right || he.nh_right) && he.last;
 	e.zero = he.wrap == W_ZERO;
 	return e;
 }
@@ -576,7 +576,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		return;  // units come in pairs, so both waves of a pair leave together (a barrier does not wait for ended waves)
 	const int lane = threadIdx.x & 63;
 	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
-	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	bool hedge_ = lc.hedge;
+#ifdef AKO_EXP_NOHEDGE  // experiments (timing only, wrong pixels at the borders): border strips / segments run the interior bodies
+	hedge_ = false;
+#endif
+#ifdef AKO_EXP_NOVEDGE
+	vedge = false;
+#endif
 	// (strip and segment are the pair's: both its waves take the same way, and execute the same sequence of barriers)
 #define AKO_INV_LEAN(H, V)                                                       \
 	do                                                                           \
@@ -588,14 +595,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	} while (0)
 	if (__builtin_expect(vedge, 0))
 	{
-		if (lc.hedge)
+		if (hedge_)
 			AKO_INV_LEAN(true, true);
 		else
 			AKO_INV_LEAN(false, true);
 	}
 	else
 	{
-		if (lc.hedge)
+		if (hedge_)
 			AKO_INV_LEAN(true, false);
 		else
 			AKO_INV_LEAN(false, false);
@@ -849,7 +856,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		return;
 	const int lane = threadIdx.x & 63;
 	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
-	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	bool hedge_ = lc.hedge;
+#ifdef AKO_EXP_NOHEDGE  // experiments (timing only, wrong pixels at the borders): border strips / segments run the interior bodies
+	hedge_ = false;
+#endif
+#ifdef AKO_EXP_NOVEDGE
+	vedge = false;
+#endif
 #define AKO_FWD_LEAN(H, V)                                                   \
 	do                                                                       \
 	{                                                                        \
@@ -860,14 +874,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	} while (0)
 	if (__builtin_expect(vedge, 0))
 	{
-		if (lc.hedge)
+		if (hedge_)
 			AKO_FWD_LEAN(true, true);
 		else
 			AKO_FWD_LEAN(false, true);
 	}
 	else
 	{
-		if (lc.hedge)
+		if (hedge_)
 			AKO_FWD_LEAN(true, false);
 		else
 			AKO_FWD_LEAN(false, false);

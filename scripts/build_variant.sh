@@ -17,5 +17,5 @@ if [ $WHICH != rgba ]; then PLAN=$O/ako_plan_$NAME.o; $CC "$@" -c ako_amd/csrc/a
 if [ $WHICH != plan ]; then RGBA=$O/ako_u8_rgba_$NAME.o; $CC "$@" -c ako_amd/csrc/ako_u8_rgba.hip -o $RGBA & fi
 if [ $WHICH = all ]; then RGB=$O/ako_u8_rgb_$NAME.o; $CC "$@" -c ako_amd/csrc/ako_u8_rgb.hip -o $RGB & fi
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ako_amd/libako_$NAME.so $PLAN $O/ako_copy.hip.o $RGBA $RGB $O/ako_quant.c.o $O/ako_head.c.o $O/ako_misc.c.o $O/ako_kagari.c.o $O/ako_codec.c.o $O/ako_synth.c.o $O/ako_batch.c.o -lm -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ako_amd/libako_$NAME.so $PLAN $O/ako_copy.hip.o $O/ako_u8_gray.hip.o $RGBA $RGB $O/ako_quant.c.o $O/ako_head.c.o $O/ako_misc.c.o $O/ako_kagari.c.o $O/ako_codec.c.o $O/ako_synth.c.o $O/ako_batch.c.o -lm -lpthread
 echo built ako_amd/libako_$NAME.so
