@@ -14,6 +14,9 @@ KINDS = ["dd137", "cdf53", "haar"]
 
 
 def label(name, workload):
+    m = re.search(r"k_(forward|inverse)_u8_(?:lean|gray)<(\d)", name)  # round 4: the lean / gray level-0 kernels report under the same record names
+    if m:
+        return ("fwd" if m.group(1) == "forward" else "inv") + "_stream_" + KINDS[int(m.group(2))] + "_u8:0"
     m = re.search(r"k_(forward|inverse)_stream_u8<(\d)", name)
     if m:
         return ("fwd" if m.group(1) == "forward" else "inv") + "_stream_" + KINDS[int(m.group(2))] + "_u8:0"
@@ -38,7 +41,7 @@ for arg in sys.argv[4:]:
     res, tot_f16, tot_f4, total_w = {}, 0.0, 0.0, 0.0
     for name in set(fetch) | set(write):
         f, w = fetch.get(name, []), write.get(name, [])
-        dword_reader = "k_inverse_stream" in name or "k_fused2_inverse" in name  # a dword per lane and sub-band row
+        dword_reader = "k_inverse_stream" in name or "k_fused2_inverse" in name or "k_inverse_u8_" in name  # a dword per lane and sub-band row
         if dword_reader:
             tot_f4 += sum(f)
         else:
