@@ -48,12 +48,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # what holds the u8 level-0 kernels up (profiles/r4_issue_model.txt); quoted in the roofline block when one of
 # them is the dominant kernel
-BINDING_U8_LEVEL0 = ("per-wave instruction issue, not HBM and not the VALU pipe's throughput: a wave spends ~65 % of its life in its "
-                     "VALU phases at 4.5 (plain fp32) to 13 (byte conversions, SDWA, DPP) cycles per instruction, 10 % at barriers, "
-                     "< 5 % waiting for memory; four waves per SIMD keep the pipe ~55 % busy (SQ_ACTIVE_INST_VALU counts quad-cycles: "
-                     "0.27 per wave = one issue slot per instruction, the pipe retires a wave64 instruction in 2 cycles), and the "
-                     "launch ends with its slowest waves (lifetimes 80 k / 188 k / 292 k cycles min / median / max); "
-                     "profiles/r4_phase_stamps.txt, r4_sq_counters.txt, r4_effective_clock.txt.  'frac' is what that leaves of HBM")
+BINDING_U8_LEVEL0 = ("the SIMD's VALU pipe shared by the four resident waves, not HBM: a wave spends 85 % (forward) / 65 % (inverse) of "
+                     "its life in VALU phases, 10 % / 23 % at barriers, < 5 % waiting for memory; inside the VALU phases the four waves "
+                     "run AT the pipe bound (2 cycles per plain wave64 instruction, 4 per DPP / SDWA / conversion: 3 002 cycles per row "
+                     "slot predicted from the ISA, 3 156 stamped), and over the whole launch the pipe is 49 % occupied: the rest is "
+                     "barriers, pipeline fill and the launch's tail (wave lifetimes 80 k / 188 k / 292 k cycles min / median / max, "
+                     "1.98 rounds of resident waves).  SQ_ACTIVE_INST_VALU counts quad-cycles: 0.27 per wave = one issue slot per "
+                     "instruction.  profiles/r4_issue_model.txt, r4_phase_stamps.txt, r4_sq_counters.txt, r4_effective_clock.txt.  "
+                     "'frac' is what that leaves of HBM")
 
 WORKLOADS = {
     "full8192": "configs[2]: full path YCoCg_Q + DD13/7 + q16 + g16, one 8192x8192 RGBA image per GPU, single tile, "
@@ -61,9 +63,13 @@ WORKLOADS = {
     "rgb8192": "extra: one 8192x8192 RGB (3 channel) image, DD13/7 q16 g16",
     "batch4k": "configs[3] share: 8 x 3840x2160 RGBA images per GPU, DD13/7 q16 g16",
     "lift4096": "configs[1]: DD13/7 lift + unlift of one 4096x4096 int16 plane",
-    "tiles16k": "configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles 512 (AKO_BENCH_TILES), tile rows "
+    "tiles16k": "configs[4]: one 16384x16384 RGBA image, CDF5/3 lossless, tiles {tiles} (AKO_BENCH_TILES), tile rows "
                 "split over the ranks, round trip checked bit-exact",
 }
+
+
+def workload_label(name):
+    return WORKLOADS[name].replace("{tiles}", os.environ.get("AKO_BENCH_TILES", "512"))
 
 
 def parse(argv=None):
@@ -257,6 +263,8 @@ def measured_traffic(workload, kernel, level):
         return None, "profiles/traffic.json missing"
     try:
         t = json.load(open(path))
+        if workload == "tiles16k":  # collected per tile size
+            workload = "tiles16k_" + os.environ.get("AKO_BENCH_TILES", "512")
         e = t.get(workload, {}).get(f"{kernel}:{level}")
         if not e:
             return None, f"profiles/traffic.json has no entry for {workload} / {kernel}:{level}"
@@ -299,7 +307,7 @@ def rehearsal_without_gpu(args, rank, world):
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "int32",
                           "data": "rehearsal without a GPU: empty steps, launcher and harness only",
-                          "config": {"workload": WORKLOADS[args.workload]}}), flush=True)
+                          "config": {"workload": workload_label(args.workload)}}), flush=True)
     if world > 1:
         import torch.distributed as dist
 
@@ -663,7 +671,7 @@ def main():
             "value_inflight1": round(value1, 2),
             "ms_per_step_inflight1": round(elapsed1 / args.steps * 1e3, 4),
             "verified_against_reference_checksums": verified,
-            "config": {"workload": WORKLOADS[args.workload], "pixels_per_gpu_step": pixels, "channels": ch,
+            "config": {"workload": workload_label(args.workload), "pixels_per_gpu_step": pixels, "channels": ch,
                        "parallelism": f"images x{world}", "steps_in_flight": nfl,
                        "distinct_input_per_slot": True},
             "roofline": {
