@@ -501,6 +501,9 @@ struct UnitId
 {
 	uint32_t strip, seg, pg, tile, image;
 	bool valid;
+#if defined(AKO_STAMPS) && AKO_STAMPS == 2
+	unsigned long long t_top, t_dec, t_lc;  // (measurement builds: s_memtime at the kernel's first instruction, after decode_unit(), after lane_columns())
+#endif
 };
 
 template <typename T>

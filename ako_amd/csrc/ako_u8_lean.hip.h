@@ -52,6 +52,9 @@ static_assert(2 * XI_BUF * sizeof(float) == INV_U8_LDS_PER_PAIR, "same LDS per p
 // akoHipLeanStamps().  Every stamp first pins the values of the phase it closes (AKO_PIN: otherwise instruction selection
 // computes them where they are used, phases later).  The shipped library holds none of this.
 #ifdef AKO_STAMPS
+#if AKO_STAMPS != 2
+#define AKO_STAMPS_PHASES 1  // (the slots' bodies split into phases; -DAKO_STAMPS=2 leaves them as shipped)
+#endif
 constexpr int STAMP_WAVES = 16384;  // (a row per wave: 8 000 waves adding to sixteen shared words serialise for a millisecond)
 __device__ unsigned long long ako_lean_stamps[2][STAMP_WAVES][12];  // [10], [11]: birth and end of the row's latest wave (absolute)
 // One slot in six is stamped (unroll position 0), and a slot's stamps are only read at its end: s_memtime answers through the
@@ -125,6 +128,46 @@ __device__ unsigned long long ako_lean_stamps[2][STAMP_WAVES][12];  // [10], [11
 		if constexpr ((K_) == 0)                                                             \
 			__builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));             \
 	} while (0)
+#if AKO_STAMPS == 2
+// -DAKO_STAMPS=2: only birth, end and PLACE of every wave (HW_ID: wave slot / SIMD / CU / SE, XCC_ID; workgroup and wave in it):
+// two s_memtime per wave, the slots untouched (scripts/wave_places.py: who shared a SIMD with whom, and for how long)
+#undef AKO_STAMP_DECL
+#undef AKO_STAMP_K
+#undef AKO_STAMP_SLOT_BEGIN
+#undef AKO_STAMP_SLOT_END
+#undef AKO_STAMP_NOW
+#undef AKO_STAMP_FLUSH
+#undef AKO_PIN4
+#undef AKO_WAIT_VM
+#define AKO_STAMP_DECL const unsigned long long st_born = __builtin_amdgcn_s_memtime()
+#define AKO_STAMP_TOP const unsigned long long st_top_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define AKO_STAMP_TOP_SET(id_) (id_).t_top = st_top_, (id_).t_dec = __builtin_amdgcn_s_memtime()
+#define AKO_STAMP_LC_SET(id_) __builtin_amdgcn_sched_barrier(0); (id_).t_lc = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define AKO_STAMP_K(i, K_)
+#define AKO_STAMP_SLOT_BEGIN(K_)
+#define AKO_STAMP_SLOT_END(K_, first, last)
+#define AKO_STAMP_NOW(i)
+#define AKO_PIN4(a)
+#define AKO_WAIT_VM(n, K_)
+#define AKO_STAMP_FLUSH(dir)                                                                                           \
+	do                                                                                                                 \
+	{                                                                                                                  \
+		const unsigned hw_ = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc_ = __builtin_amdgcn_s_getreg(20 | (31 << 11)); \
+		if (lane == 0)                                                                                                 \
+		{                                                                                                              \
+			unsigned long long* row_ = ako_lean_stamps[dir][(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % STAMP_WAVES]; \
+			const unsigned long long st_end = __builtin_amdgcn_s_memtime();                                            \
+			row_[0] = hw_, row_[1] = xcc_, row_[2] = blockIdx.x, row_[3] = threadIdx.x >> 6;                           \
+			row_[4] = id.strip, row_[5] = id.seg | ((unsigned long long)(id.t_dec - id.t_top) << 32),                  \
+			row_[6] = id.pg | ((unsigned long long)(id.t_lc - id.t_top) << 32), row_[7] = (HEDGE ? 1 : 0) | (VEDGE ? 2 : 0); \
+			__builtin_amdgcn_s_waitcnt(0x0F70);  /* vmcnt(0): the wave's last stores acknowledged */                     \
+			const unsigned long long st_drained = __builtin_amdgcn_s_memtime();                                        \
+			row_[8] = id.t_top;                                                                                        \
+			row_[9] = st_drained;                                                                                      \
+			row_[10] = st_born, row_[11] = st_end;                                                                     \
+		}                                                                                                              \
+	} while (0)
+#endif
 #else
 #define AKO_STAMP_DECL
 #define AKO_STAMP(i)
@@ -430,7 +473,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 		AKO_WAIT_VM(4 * NP * AKO_U8L_INV_PF + 1, K);  // (stamps: everything but the slots fetched ahead and the last pixel store)
 		AKO_STAMP(0);
 		column_pass(kc, v, raw, ev, od);
-#ifdef AKO_STAMPS
+#ifdef AKO_STAMPS_PHASES
 		for (int p = 0; p < NP; p++)
 		{
 			AKO_PIN4(ev[p]);
@@ -456,7 +499,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 				hlift_inverse_bf<KIND, HEDGE, float>(od[p][0], od[p][1], od[p][2], od[p][3], he, me[0], me[1], me[2], me[3]);
 			}
 		}
-#ifdef AKO_STAMPS
+#ifdef AKO_STAMPS_PHASES
 		for (int p = 0; p < NP; p++)
 		{
 			AKO_PIN4(mine[p]);
@@ -477,7 +520,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 				his[p][k] = xr[(K & 1) * XI_BUF + p * XI_PLANE + k * 64];
-#ifdef AKO_STAMPS
+#ifdef AKO_STAMPS_PHASES
 		for (int p = 0; p < NP_HIS; p++)
 			AKO_PIN4(his[p]);
 #endif
@@ -571,13 +614,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 {
 	extern __shared__ float xlean[];
 	float* xb = xlean + (threadIdx.x >> 7) * (2 * XI_BUF);
+#if defined(AKO_STAMPS) && AKO_STAMPS == 2
+	AKO_STAMP_TOP;
+	UnitId id = decode_unit(P, G);
+	AKO_STAMP_TOP_SET(id);
+#else
 	const UnitId id = decode_unit(P, G);
+#endif
 	if (!id.valid)
 		return;  // units come in pairs, so both waves of a pair leave together (a barrier does not wait for ended waves)
 	const int lane = threadIdx.x & 63;
 	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	bool hedge_ = lc.hedge;
+#if defined(AKO_STAMPS) && AKO_STAMPS == 2
+	asm volatile("" ::"v"(lc.c0), "v"(lc.xs));
+	AKO_STAMP_LC_SET(id);
+#endif
 #ifdef AKO_EXP_NOHEDGE  // experiments (timing only, wrong pixels at the borders): border strips / segments run the interior bodies
 	hedge_ = false;
 #endif
@@ -724,7 +777,7 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 				for (int k = 0; k < 4; k++)
 					smp[par][0][k] = zero_row ? 0.0f : smp[par][0][k], smp[par][1][k] = zero_row ? 0.0f : smp[par][1][k];
 		}
-#ifdef AKO_STAMPS
+#ifdef AKO_STAMPS_PHASES
 		for (int p = 0; p < NP; p++)
 		{
 			AKO_PIN4(smp[0][p]);
@@ -742,13 +795,13 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 		{
 			hlift_forward_bf<KIND, HEDGE, float>(smp[0][p][0], smp[0][p][1], smp[0][p][2], smp[0][p][3], he, e[p][0], e[p][1], e[p][2], e[p][3]);
 			hlift_forward_bf<KIND, HEDGE, float>(smp[1][p][0], smp[1][p][1], smp[1][p][2], smp[1][p][3], he, o[p][0], o[p][1], o[p][2], o[p][3]);
-#ifndef AKO_STAMPS
+#ifndef AKO_STAMPS_PHASES
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 				vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
 #endif
 		}
-#ifdef AKO_STAMPS
+#ifdef AKO_STAMPS_PHASES
 		for (int p = 0; p < NP; p++)
 		{
 			AKO_PIN4(e[p]);
@@ -780,7 +833,7 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 			// LL = (LP rows, LP cols), C = (HP rows, LP cols), B = (LP rows, HP cols), D = (HP, HP); gate + quantizer: lifting.c:154-168
 			uint32_t w_ll, w_c, w_b, w_d;
 			pack_row_f(lp[p], hp[p], gf[p], rq[p], w_ll, w_c, w_b, w_d);
-#ifdef AKO_STAMPS
+#ifdef AKO_STAMPS_PHASES
 			asm volatile("" ::"v"(w_ll), "v"(w_c), "v"(w_b), "v"(w_d));
 			if (p == NP - 1)
 				AKO_STAMP(4);
@@ -851,13 +904,23 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 template <int KIND, int CH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_forward_u8_lean(const LevelParams P, const StreamGeom G)
 {
+#if defined(AKO_STAMPS) && AKO_STAMPS == 2
+	AKO_STAMP_TOP;
+	UnitId id = decode_unit(P, G);
+	AKO_STAMP_TOP_SET(id);
+#else
 	const UnitId id = decode_unit(P, G);
+#endif
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
 	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	bool hedge_ = lc.hedge;
+#if defined(AKO_STAMPS) && AKO_STAMPS == 2
+	asm volatile("" ::"v"(lc.c0), "v"(lc.xs));
+	AKO_STAMP_LC_SET(id);
+#endif
 #ifdef AKO_EXP_NOHEDGE  // experiments (timing only, wrong pixels at the borders): border strips / segments run the interior bodies
 	hedge_ = false;
 #endif

@@ -79,6 +79,18 @@ extern "C" __attribute__((visibility("default"))) int akoHipLeanStamps(unsigned 
 				out[20 + ((size_t)d * ako::STAMP_WAVES + w) * 2 + 0] = h[((size_t)d * ako::STAMP_WAVES + w) * 12 + 10];
 				out[20 + ((size_t)d * ako::STAMP_WAVES + w) * 2 + 1] = h[((size_t)d * ako::STAMP_WAVES + w) * 12 + 11];
 			}
+	// reset & 4 (-DAKO_STAMPS=2 builds): twelve values per row instead -- birth, end, HW_ID, XCC_ID, workgroup, wave in it, strip,
+	// segment, role, border flags
+	if (reset & 4)
+		for (int d = 0; d < 2; d++)
+			for (int w = 0; w < ako::STAMP_WAVES; w++)
+			{
+				const unsigned long long* r = h + ((size_t)d * ako::STAMP_WAVES + w) * 12;
+				unsigned long long* o = out + 20 + ((size_t)d * ako::STAMP_WAVES + w) * 12;
+				o[0] = r[10], o[1] = r[11];
+				for (int i = 0; i < 10; i++)
+					o[2 + i] = r[i];  // ... [10] kernel entry, [11] last stores acknowledged
+			}
 	int rc = 0;
 	if (reset & 1)
 	{
