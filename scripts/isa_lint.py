@@ -37,6 +37,7 @@ LABEL = re.compile(r"^(\.LBB\d+_\d+):")
 BRANCH = re.compile(r"^\s+s_c?branch\S*\s+(\.LBB\d+_\d+)")
 KERNEL = re.compile(r"^(_Z\S+):\s*(;.*)?$")
 MARK = re.compile(r";\s*AKO_LOOP\s+(\S+)")
+END = re.compile(r";\s*AKO_LOOP_END\b")
 INSTR = re.compile(r"^\s+([a-z][a-z0-9_]+)\b(.*)$")
 
 
@@ -104,9 +105,13 @@ def analyse(path: str):
             if tgt is not None and tgt < i:
                 loops.append((tgt, i))
     marks = [(i, MARK.search(ln).group(1)) for i, ln in enumerate(lines) if MARK.search(ln)]
+    ends = [i for i, ln in enumerate(lines) if END.search(ln)]
     out = []
     for at, name in marks:
-        inside = [(lo, hi) for lo, hi in loops if lo <= at <= hi]
+        # a trip inside a bigger loop (the queue kernels: claims, runs, trips) says where it ends itself
+        nxt = min([m for m, _ in marks if m > at], default=len(lines))
+        stop = [e for e in ends if at < e < nxt]
+        inside = [(at, stop[0])] if stop else [(lo, hi) for lo, hi in loops if lo <= at <= hi]
         if not inside:
             out.append({"loop": name, "file": os.path.basename(path), "error": "marker is not inside a loop"})
             continue
