@@ -524,10 +524,11 @@ bool stream_eligible(const akoHipPlan* pl, const LevelGeom& L, bool u8)
 uint64_t scratch_plane_elems(const Group& g, int which);
 
 // Small tiles side by side in one wave (lane_columns_pack in ako_stream.hip.h): int16 levels of 8, 16, 32 or 64 coefficient
-// columns with an even width, any border rule but REPEAT, more than one tile in the group; returns the tiles per wave (0: no)
+// columns with an even width, any border rule (REPEAT since round 4: every lane fetches its own tile's other end by
+// ds_bpermute), more than one tile in the group; returns the tiles per wave (0: no)
 uint32_t tile_pack(const akoHipPlan* pl, const Group& g, const LevelGeom& L, bool u8)
 {
-	if (!pl->tune.pack || u8 || pl->s.wrap == AKO_WRAP_REPEAT || g.tiles.size() < 2)
+	if (!pl->tune.pack || u8 || g.tiles.size() < 2)
 		return 0;
 	if (L.tw < 4 || L.tw > 64 || (L.tw & (L.tw - 1)) != 0 || L.cw != 2 * L.tw || L.th < 2)
 		return 0;

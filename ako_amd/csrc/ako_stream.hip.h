@@ -204,6 +204,7 @@ struct HEdge
 	bool nh_left, nh_right;  // "wide" strips: the border sits at lane 0 / lane 63, there are no out-of-range lanes on
 	                         // that side to hold the border values (see edge_taps)
 	int lane_first, lane_last;
+	bool rep_lanes;  // REPEAT over several tiles in one wave (lane_columns_pack): lane_first / lane_last are THIS lane's tile's, fetched by ds_bpermute
 	int wrap;
 	int perm_prev, perm_next;  // AKO_PERM: 4 * (lane - 1), 4 * (lane + 1) (mod 64): ds_bpermute addresses of the neighbours
 };
@@ -232,6 +233,16 @@ __device__ __forceinline__ void fix_halo_lanes(V& a0, V& a1, const HEdge& ed)
 // a1 = column c1): prev1 / prev2 = columns c0-1 / c0-2 as seen by the FIRST lane, next1 / next2 = columns
 // c1+1 / c1+2 as seen by the LAST lane.  CLAMP and MIRROR take the nearest in-range value (MIRROR's far
 // taps are substituted by the callers as everywhere else), ZERO takes 0, REPEAT the other end.
+// the value lane 'src' holds (src: any lane, per lane)
+__device__ __forceinline__ int from_lane(int x, int src)
+{
+	return __builtin_amdgcn_ds_bpermute(src * 4, x);
+}
+__device__ __forceinline__ float from_lane(float x, int src)
+{
+	return __int_as_float(__builtin_amdgcn_ds_bpermute(src * 4, __float_as_int(x)));
+}
+
 template <typename V>
 struct BorderVals
 {
@@ -243,6 +254,11 @@ __device__ __forceinline__ BorderVals<V> border_values(V a0, V a1, const HEdge& 
 	BorderVals<V> b;
 	if (ed.wrap == W_ZERO)
 		b.prev1 = b.prev2 = b.next1 = b.next2 = (V)0;
+	else if (ed.wrap == W_REPEAT && ed.rep_lanes)  // several tiles side by side: every lane asks its own tile's other end
+	{
+		b.prev1 = from_lane(a1, ed.lane_last), b.prev2 = from_lane(a0, ed.lane_last);
+		b.next1 = from_lane(a0, ed.lane_first), b.next2 = from_lane(a1, ed.lane_first);
+	}
 	else if (ed.wrap == W_REPEAT)
 	{
 		b.prev1 = read_lane(a1, ed.lane_last), b.prev2 = read_lane(a0, ed.lane_last);
@@ -672,6 +688,7 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 	lc.he.oob_r = lc.c0 >= Tc;
 	lc.he.lane_first = wide ? 0 : SORG / 2;
 	lc.he.lane_last = (Tc - 2 - c_base) / 2;
+	lc.he.rep_lanes = false;
 	lc.he.first = (lc.c0 == 0);
 	lc.he.last = (lc.c0 == Tc - 2);
 	// Odd Tc, in a strip that is not the (shifted) last one: the lane at c0 == Tc - 1 would straddle the border.
@@ -735,6 +752,7 @@ __device__ __forceinline__ LaneCols lane_columns_row(uint32_t strip, int lane, i
 	lc.he.nh_left = lc.he.nh_right = true;
 	lc.he.oob_l = lc.he.oob_r = false;
 	lc.he.lane_first = 0, lc.he.lane_last = 0;
+	lc.he.rep_lanes = false;
 	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
 	lc.he.first = (lc.c0 == 0);
 	lc.he.last = (lc.c0 == Tc - 2);
@@ -757,7 +775,9 @@ __device__ __forceinline__ LaneCols lane_columns_pack(int lane, int Tc, int wrap
 	lc.he.left = lc.he.right = false;
 	lc.he.nh_left = lc.he.nh_right = true;
 	lc.he.oob_l = lc.he.oob_r = false;
-	lc.he.lane_first = 0, lc.he.lane_last = 0;  // (only read for REPEAT and for out-of-range lanes: neither exists here)
+	// REPEAT: the other end of the lane's own tile (border_values through ds_bpermute)
+	lc.he.lane_first = lc.tile_in_pack * lpt, lc.he.lane_last = lc.he.lane_first + lpt - 1;
+	lc.he.rep_lanes = (wrap == W_REPEAT);
 	lc.he.perm_prev = ((lane + 63) & 63) * 4, lc.he.perm_next = ((lane + 1) & 63) * 4;
 	lc.he.first = (lc.c0 == 0);
 	lc.he.last = (lc.c0 == Tc - 2);
@@ -785,6 +805,7 @@ __device__ __forceinline__ LaneCols lane_columns_at(int c_base, int net_lo, int 
 	lc.he.oob_r = lc.c0 >= Tc;
 	lc.he.lane_first = (c_base < 0) ? (-c_base) / 2 : 0;
 	lc.he.lane_last = (Tc - 2 - c_base) / 2;
+	lc.he.rep_lanes = false;
 	lc.he.first = (lc.c0 == 0);
 	lc.he.last = (lc.c0 == Tc - 2);
 	lc.he.half = false, lc.he.drop_last = false;
