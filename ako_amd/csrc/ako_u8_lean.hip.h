@@ -3,8 +3,8 @@
 // Same strip walk, same arithmetic and same results as k_forward_stream_u8 / k_inverse_stream_u8 (ako_stream.hip.h: one
 // wave64 per strip of 128 coefficient columns and pair of planes, rows in registers, taps through DPP shifts, column pass
 // as a register pipeline), for the configurations that carry practically all pixels: YCoCg / YCoCg_Q colour, DD13/7 or
-// CDF5/3, CLAMP / REPEAT / ZERO borders, level widths that are multiples of four, ordinary strips (no wide strip, no
-// row strips over tiles).  Everything else -- MIRROR, Haar, other colour modes, the discard rule, odd widths, packed
+// CDF5/3, CLAMP / REPEAT / ZERO borders, level widths that are multiples of four, ordinary strips and (not REPEAT) the one
+// wide strip of a tile of 121..128 columns (256-pixel tiles); no row strips over tiles.  Everything else -- MIRROR, Haar, other colour modes, the discard rule, odd widths, packed
 // tiles -- stays on the general kernels, which the host picks per launch (ako_plan.hip: lean_u8_level()).
 //
 // Why a second pair of kernels (measured on one box in one call, profiles/r4_lean_ab.txt):
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	if (!id.valid)
 		return;  // units come in pairs, so both waves of a pair leave together (a barrier does not wait for ended waves)
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide == 1u, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	bool hedge_ = lc.hedge;
 #if defined(AKO_STAMPS) && AKO_STAMPS == 2
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	if (!id.valid)
 		return;
 	const int lane = threadIdx.x & 63;
-	const LaneCols lc = lane_columns(id.strip, G.strips, false, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
+	const LaneCols lc = lane_columns(id.strip, G.strips, G.wide == 1u, lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
 	bool hedge_ = lc.hedge;
 #if defined(AKO_STAMPS) && AKO_STAMPS == 2
