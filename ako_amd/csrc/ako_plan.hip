@@ -773,12 +773,12 @@ void launch_inverse_stream(int kind, const LevelParams& P, const StreamGeom& G, 
 // May this u8 level launch run on the lean kernels (ako_u8_lean.hip.h)?  They hold what carries practically all pixels --
 // YCoCg / YCoCg_Q without the discard rule, DD13/7 or CDF5/3, CLAMP / REPEAT / ZERO, a level width that is a multiple of
 // four (even number of coefficient columns, no phantom sample), ordinary strips or ONE wide strip (a tile of 121..128 columns;
-// not with REPEAT, which needs the other end of the wave) -- and nothing else; MIRROR, Haar, other colour modes, odd widths and
-// row strips over tiles stay on the general kernels.
+// not with REPEAT, which needs the other end of the wave) or strips over whole rows of tiles (never REPEAT: row_strips()) -- and
+// nothing else; MIRROR, Haar, other colour modes, odd widths and packed small tiles stay on the general kernels.
 bool lean_u8_level(const akoHipPlan* pl, const LevelParams& P, const StreamGeom& G, int kind, bool forward)
 {
 	return pl->tune.interior && (kind == K_DD137 || kind == K_CDF53) && (P.color == C_YCOCG || P.color == C_YCOCG_Q) && !(forward && P.discard != 0) &&
-	       P.wrap != W_MIRROR && (P.full_w & 3u) == 0 && P.full_w == 2 * P.sub_w && (G.wide == 0 || (G.wide == 1 && P.wrap != W_REPEAT));
+	       P.wrap != W_MIRROR && (P.full_w & 3u) == 0 && P.full_w == 2 * P.sub_w && (G.wide == 0 || (G.wide == 1 && P.wrap != W_REPEAT) || (G.wide >> 31) != 0);
 }
 
 void launch_inverse_u8(const akoHipPlan* pl, bool opt, int kind, const LevelParams& P, const StreamGeom& G, uint32_t blocks)

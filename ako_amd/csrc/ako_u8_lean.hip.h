@@ -353,7 +353,7 @@ __device__ __forceinline__ void vstep_inverse_bf(VInv<V>& s, V LP, V HP, int v, 
 // Inverse.  Role 0 carries planes 0, 1 (Y, Co) and finishes the even pixel row of a slot, role 1 planes 2, 3 (Cg, alpha;
 // RGB: Cg alone) and the odd row; the rows' other planes cross through LDS (one barrier per slot, double buffered).
 // =====================================================================================================================
-template <int KIND, int CH, int ROLE, bool HEDGE, bool VEDGE>
+template <int KIND, int CH, int ROLE, bool HEDGE, bool VEDGE, bool ROWS = false>
 __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const StreamGeom& G, const UnitId& id, const LaneCols& lc, int lane,
                                                 float* xb)
 {
@@ -372,15 +372,25 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	segment_rows(G, id.seg, Tr, r_lo, r_hi, seg_len);
 	(void)seg_len;
 
-	const int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
+	// ROWS: strips laid over a whole row of tiles (lane_columns_row; level 0 of 512-pixel tiles): tile borders fall on any lane, the
+	// border rule is the same tap substitution as at a strip's border; the resources are based at the image's stream / first
+	// tile instance and the lane's byte offsets carry its own tile's stream offset and low-pass plane
+	static_assert(!ROWS || HEDGE, "every strip over a row of tiles holds tile borders");
+	const uint32_t lane_tile = ROWS ? min(id.tile + (uint32_t)lc.tile_in_pack, P.n_tiles - 1u) : 0u;  // per lane
+	const uint64_t base_inst = ROWS ? (uint64_t)id.image * P.n_tiles : inst;
+	const uint32_t lane_stream_b = ROWS ? (uint32_t)(P.tiles[lane_tile].stream_off * 2) : 0u;  // per lane
+	const int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + (ROWS ? 0 : td.stream_off);
 	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(tile_stream), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
-	const int16_t* ll_root = P.ll_in_stream ? tile_stream : (P.src + inst * P.src_inst_stride);
+	const int16_t* ll_root = P.ll_in_stream ? tile_stream : (P.src + base_inst * P.src_inst_stride);
 	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(ll_root), 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
 	const uint32_t ll_pitch_b = (P.ll_in_stream ? (uint32_t)Tc : P.src_pitch) * 2u;
 	const uint32_t sub_pitch_b = (uint32_t)Tc * 2u;
 	const uint32_t nsub_b = (uint32_t)((uint64_t)Tc * Tr * 2);
 	// (lanes beyond a tile border read their clamped / wrapped pair, lane_columns(); HEDGE patches them for every rule but REPEAT)
-	const uint32_t lane_in_off = (uint32_t)lc.cs * 2u;
+	const uint32_t lane_in_off = (uint32_t)lc.cs * 2u + lane_stream_b;
+	const uint32_t lane_ll_in_off = !ROWS ? lane_in_off
+	                                      : (uint32_t)lc.cs * 2u + (P.ll_in_stream ? lane_stream_b : lane_tile * (uint32_t)P.src_inst_stride * 2u);
+	bool heads_differ = false;  // ROWS: the tiles of a wave carry one lift head each
 
 	uint32_t ll_off[NP], grp_off[NP];
 	float qf[NP];
@@ -389,7 +399,13 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	{
 		const int pl = 2 * ROLE + p;
 		// the decoder trusts the lift head (misc.c:266-272, lifting.c:114-116); one tile per wave: wave-uniform
-		const int q = __builtin_amdgcn_readfirstlane((int)tile_stream[P.grp_off[pl]]);
+		// ROWS: one head per tile.  An honest stream repeats the same value in every tile of a level and plane; where the tiles
+		// of this wave disagree the wave gives up like on an input beyond its proof bound, and the exact kernel behind this one,
+		// which de-quantizes per lane, does the level
+		const int q_lane = (int)(tile_stream + (lane_stream_b >> 1))[P.grp_off[pl]];
+		const int q = __builtin_amdgcn_readfirstlane(q_lane);
+		if constexpr (ROWS)
+			heads_differ = heads_differ || (q_lane != q);
 		qf[p] = (q > 1) ? (float)q : 1.0f;  // lifting.c:30-40: multiply only when q > 1
 		grp_off[p] = (uint32_t)((P.grp_off[pl] + 1) * 2);
 		ll_off[p] = (uint32_t)((P.ll_in_stream ? P.lp_off[pl] : (uint64_t)pl * P.src_plane_stride) * 2);
@@ -399,7 +415,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	const uint32_t out_pitch_b = P.img_pitch * (uint32_t)CH;
 	const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (int)0xFFFFFFFFu, RSRC_FLAGS);
 	const bool store_lane = lc.net && (lc.c0 >= 0) && (lc.c0 < Tc);
-	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * lc.c0) * (uint32_t)CH : OOB;
+	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * (ROWS ? (lc.xs >> 1) : lc.c0)) * (uint32_t)CH : OOB;  // (ROWS: the column inside the row of tiles)
 	const float ysc = (P.color == C_YCOCG_Q) ? 0.5f : 1.0f;  // format.c:170: y = in / 2 first
 
 	VInv<float> st[NP][4];
@@ -425,7 +441,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 		for (int p = 0; p < NP; p++)
 		{
 			const uint32_t g = grp_off[p] + row_g;
-			raw.ll[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_ll, lane_in_off, ll_off[p] + row_l, 0);
+			raw.ll[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_ll, lane_ll_in_off, ll_off[p] + row_l, 0);
 			raw.c[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g, AUX_INV_STREAM_LOAD);
 			raw.b[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + nsub_b, AUX_INV_STREAM_LOAD);
 			raw.d[p] = __builtin_amdgcn_raw_buffer_load_b32(rs_stream, lane_in_off, g + 2u * nsub_b, AUX_INV_STREAM_LOAD);
@@ -593,7 +609,12 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	for (int base = 6; base < n_slots; base += 6)
 	{
 		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
-			asm volatile("; AKO_LOOP inv_u8_lean_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+		{
+			if constexpr (ROWS)
+				asm volatile("; AKO_LOOP inv_u8_rows_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+			else
+				asm volatile("; AKO_LOOP inv_u8_lean_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+		}
 		static_for<6>([&](auto kc) {
 			constexpr int K = decltype(kc)::value;
 			const int v = v_begin + base + K;
@@ -602,7 +623,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 			full_slot(kc, v, ring[K % (PF + 1)]);
 		});
 	}
-	const bool bad = !(peak_in <= OPT_INPUT_BOUND_TIGHT);  // negated: NaN counts as bad
+	const bool bad = !(peak_in <= OPT_INPUT_BOUND_TIGHT) || heads_differ;  // negated: NaN counts as bad
 	if (__any(bad) && lane == 0)
 		atomicMax(P.ovf_flag, P.ovf_gen);
 	AKO_STAMP_FLUSH(1);
@@ -663,11 +684,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef AKO_INV_LEAN
 }
 
+// ROWS: level 0 in strips over whole rows of tiles (StreamGeom::wide bit 31, lane_columns_row) on the lean bodies.  Kernels of
+// their own: what these bodies need beyond the single-tile ones (two per-lane offsets) must not cost the lean kernels a register
+// -- or, worse, a private segment.
+template <int KIND, int CH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inverse_u8_rows(const LevelParams P, const StreamGeom G)
+{
+	extern __shared__ float xlean[];
+	float* xb = xlean + (threadIdx.x >> 7) * (2 * XI_BUF);
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns_row(id.strip, lane, (int)P.sub_w, (int)geom_row_tiles(G), P.wrap);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	if (id.pg == 0)
+	{
+		if (vedge)
+			inverse_u8_lean<KIND, CH, 0, true, true, true>(P, G, id, lc, lane, xb);
+		else
+			inverse_u8_lean<KIND, CH, 0, true, false, true>(P, G, id, lc, lane, xb);
+	}
+	else
+	{
+		if (vedge)
+			inverse_u8_lean<KIND, CH, 1, true, true, true>(P, G, id, lc, lane, xb);
+		else
+			inverse_u8_lean<KIND, CH, 1, true, false, true>(P, G, id, lc, lane, xb);
+	}
+}
+
 // =====================================================================================================================
 // Forward.  Role 0 carries planes 0, 2 (Y, Cg: they share t = b + Co / 2), role 1 planes 1, 3 (Co, alpha; RGB: Co alone);
 // both waves of a pair load the same pixels.
 // =====================================================================================================================
-template <int KIND, int CH, int ROLE, bool HEDGE, bool VEDGE>
+template <int KIND, int CH, int ROLE, bool HEDGE, bool VEDGE, bool ROWS = false>
 __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const StreamGeom& G, const UnitId& id, const LaneCols& lc, int lane)
 {
 	static_assert(CH == 4 || CH == 3, "RGBA or RGB");
@@ -691,19 +742,28 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 	const uint32_t src_lane_off = (uint32_t)lc.xs * (uint32_t)CH;
 
 	// destinations (see forward_stream_body: out-of-range offsets drop the stores of lanes / rows that must not store)
-	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + td.stream_off;
-	const uint64_t stream_left = (P.stream_stride - td.stream_off) * 2;  // bytes up to the end of the image's stream
+	// ROWS (strips over a whole row of tiles, see inverse_u8_lean): based at the image's stream / first tile instance, the lane's
+	// offsets carry its own tile's stream offset and low-pass plane
+	static_assert(!ROWS || HEDGE, "every strip over a row of tiles holds tile borders");
+	const uint32_t lane_tile = ROWS ? min(id.tile + (uint32_t)lc.tile_in_pack, P.n_tiles - 1u) : 0u;  // per lane
+	const uint64_t base_inst = ROWS ? (uint64_t)id.image * P.n_tiles : inst;
+	const uint32_t lane_stream_b = ROWS ? (uint32_t)(P.tiles[lane_tile].stream_off * 2) : 0u;  // per lane
+	const uint64_t tile_off = ROWS ? 0 : td.stream_off;
+	int16_t* tile_stream = P.stream + (uint64_t)id.image * P.stream_stride + tile_off;
+	const uint64_t stream_left = (P.stream_stride - tile_off) * 2;  // bytes up to the end of the image's stream
 	const __amdgpu_buffer_rsrc_t rs_stream = __builtin_amdgcn_make_buffer_rsrc(
 	    tile_stream, 0, (int)(uint32_t)(stream_left < 0xFFFFFFFFull ? stream_left : 0xFFFFFFFFull), RSRC_FLAGS);
-	int16_t* ll_root = P.ll_out_stream ? tile_stream : (P.dst + inst * P.dst_inst_stride);
-	const uint64_t ll_left = P.ll_out_stream ? stream_left : (uint64_t)P.channels * P.dst_plane_stride * 2;
+	int16_t* ll_root = P.ll_out_stream ? tile_stream : (P.dst + base_inst * P.dst_inst_stride);
+	const uint64_t ll_left = P.ll_out_stream ? stream_left : (uint64_t)P.channels * P.dst_plane_stride * 2 * (ROWS ? P.n_tiles : 1u);
 	const __amdgpu_buffer_rsrc_t rs_ll = __builtin_amdgcn_make_buffer_rsrc(
 	    ll_root, 0, (int)(uint32_t)(ll_left < 0xFFFFFFFFull ? ll_left : 0xFFFFFFFFull), RSRC_FLAGS);
 	const uint32_t ll_pitch_b = (P.ll_out_stream ? (uint32_t)Tc : P.dst_pitch) * 2u;
 	const uint32_t sub_pitch_b = (uint32_t)Tc * 2u;
 	const uint32_t nsub_b = (uint32_t)((uint64_t)Tc * Tr * 2);
 	const bool store_lane = lc.net && (lc.c0 >= 0) && (lc.c0 < Tc);
-	const uint32_t lane_off = store_lane ? (uint32_t)(lc.c0 * 2) : OOB;
+	const uint32_t lane_off = store_lane ? (uint32_t)(lc.c0 * 2) + lane_stream_b : OOB;
+	const uint32_t lane_ll_off = !ROWS ? lane_off
+	                                   : (store_lane ? (uint32_t)(lc.c0 * 2) + (P.ll_out_stream ? lane_stream_b : lane_tile * (uint32_t)P.dst_inst_stride * 2u) : OOB);
 	uint32_t ll_off[NP], grp_off[NP];
 	float gf[NP], rq[NP];
 #pragma unroll
@@ -714,8 +774,8 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 		ll_off[p] = (uint32_t)((P.ll_out_stream ? P.lp_off[pl] : (uint64_t)pl * P.dst_plane_stride) * 2);
 		gf[p] = (float)((pl == 0) ? P.g_luma : P.g_chroma);  // lifting.c:202-211: every plane but the first is "chroma"
 		rq[p] = (pl == 0) ? P.rq_luma : P.rq_chroma;
-		if (id.strip == 0 && id.seg == 0 && lane == 0)  // the lift head (lifting.c:266-267)
-			tile_stream[P.grp_off[pl]] = (int16_t)((pl == 0) ? P.q_luma : P.q_chroma);
+		if (ROWS ? (id.seg == 0 && lc.net && lc.he.first) : (id.strip == 0 && id.seg == 0 && lane == 0))  // the lift head of every tile (lifting.c:266-267)
+			(tile_stream + (lane_stream_b >> 1))[P.grp_off[pl]] = (int16_t)((pl == 0) ? P.q_luma : P.q_chroma);
 	}
 	const float ymul = (P.color == C_YCOCG_Q) ? 2.0f : 1.0f;
 
@@ -842,7 +902,7 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 			const uint32_t s_c = row_ok ? grp_off[p] + row_grp : OOB;
 			const uint32_t s_b = row_ok ? grp_off[p] + row_grp + nsub_b : OOB;
 			const uint32_t s_d = row_ok ? grp_off[p] + row_grp + 2u * nsub_b : OOB;
-			__builtin_amdgcn_raw_buffer_store_b32(w_ll, rs_ll, lane_off, s_ll, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(w_ll, rs_ll, lane_ll_off, s_ll, 0);
 			__builtin_amdgcn_raw_buffer_store_b32(w_c, rs_stream, lane_off, s_c, AUX_FWD_STREAM_STORE);
 			__builtin_amdgcn_raw_buffer_store_b32(w_b, rs_stream, lane_off, s_b, AUX_FWD_STREAM_STORE);
 			__builtin_amdgcn_raw_buffer_store_b32(w_d, rs_stream, lane_off, s_d, AUX_FWD_STREAM_STORE);
@@ -889,7 +949,12 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 	for (int base = 6; base < n_slots; base += 6)
 	{
 		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
-			asm volatile("; AKO_LOOP fwd_u8_lean_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+		{
+			if constexpr (ROWS)
+				asm volatile("; AKO_LOOP fwd_u8_rows_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+			else
+				asm volatile("; AKO_LOOP fwd_u8_lean_role%0_h%1_v%2" ::"n"(ROLE), "n"((int)HEDGE), "n"((int)VEDGE));
+		}
 		if (base == 6)
 			AKO_STAMP_NOW(7);
 		AKO_STAMP_SLOT_BEGIN(0);
@@ -950,6 +1015,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 			AKO_FWD_LEAN(false, false);
 	}
 #undef AKO_FWD_LEAN
+}
+
+template <int KIND, int CH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_forward_u8_rows(const LevelParams P, const StreamGeom G)
+{
+	const UnitId id = decode_unit(P, G);
+	if (!id.valid)
+		return;
+	const int lane = threadIdx.x & 63;
+	const LaneCols lc = lane_columns_row(id.strip, lane, (int)P.sub_w, (int)geom_row_tiles(G), P.wrap);
+	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
+	if (id.pg == 0)
+	{
+		if (vedge)
+			forward_u8_lean<KIND, CH, 0, true, true, true>(P, G, id, lc, lane);
+		else
+			forward_u8_lean<KIND, CH, 0, true, false, true>(P, G, id, lc, lane);
+	}
+	else
+	{
+		if (vedge)
+			forward_u8_lean<KIND, CH, 1, true, true, true>(P, G, id, lc, lane);
+		else
+			forward_u8_lean<KIND, CH, 1, true, false, true>(P, G, id, lc, lane);
+	}
 }
 
 }  // namespace ako

@@ -7,7 +7,11 @@ namespace ako
 
 void AKO_U8_NAME(akoLaunchForwardU8)(int kind, bool lean, const LevelParams& P, const StreamGeom& G, uint32_t blocks, uint32_t threads, hipStream_t st)
 {
-	if (lean && kind == K_DD137)
+	if (lean && geom_row_tiles(G) != 0 && kind == K_DD137)  // strips over whole rows of tiles: the ROWS bodies, kernels of their own
+		hipLaunchKernelGGL((k_forward_u8_rows<K_DD137, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
+	else if (lean && geom_row_tiles(G) != 0 && kind == K_CDF53)
+		hipLaunchKernelGGL((k_forward_u8_rows<K_CDF53, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
+	else if (lean && kind == K_DD137)
 		hipLaunchKernelGGL((k_forward_u8_lean<K_DD137, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
 	else if (lean && kind == K_CDF53)
 		hipLaunchKernelGGL((k_forward_u8_lean<K_CDF53, AKO_U8_CH>), dim3(blocks), dim3(threads), 0, st, P, G);
@@ -38,7 +42,11 @@ void AKO_U8_NAME(akoLaunchInverseU8)(int kind, bool opt, bool lean, const LevelP
 	{
 		const dim3 threads(128 * pairs);
 		const uint32_t lds = pairs * INV_U8_LDS_PER_PAIR;
-		if (kind == K_DD137)
+		if (geom_row_tiles(G) != 0 && kind == K_DD137)
+			hipLaunchKernelGGL((k_inverse_u8_rows<K_DD137, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
+		else if (geom_row_tiles(G) != 0)
+			hipLaunchKernelGGL((k_inverse_u8_rows<K_CDF53, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
+		else if (kind == K_DD137)
 			hipLaunchKernelGGL((k_inverse_u8_lean<K_DD137, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);
 		else
 			hipLaunchKernelGGL((k_inverse_u8_lean<K_CDF53, AKO_U8_CH>), dim3(blocks), threads, lds, st, P, G);

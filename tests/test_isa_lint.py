@@ -62,6 +62,18 @@ def test_lean_kernels_have_no_private_segment(built):
             assert scratch == 0, (name, scratch)
             assert vgpr <= 128, (name, vgpr)  # four waves per SIMD
         assert seen == 4, (path, seen)  # forward + inverse, DD13/7 + CDF5/3
+        # the same bodies over whole rows of tiles (k_*_u8_rows): kernels of their own so that the two per-lane offsets they add
+        # cannot cost the lean kernels a register; themselves allowed one parked register (the DD13/7 inverse parks a register of
+        # spilled scalars around its row loop: 8 bytes)
+        rows = 0
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+            name, body = m.group(1), m.group(2)
+            if "u8_rows" not in name:
+                continue
+            rows += 1
+            assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) <= 8, name
+            assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 128, name
+        assert rows == 4, (path, rows)
         for m in re.finditer(r"- \.args:.*?\.name:\s+(\S+).*?\.vgpr_spill_count:\s+(\d+)", txt, re.S):
             if "u8_lean" in m.group(1):
                 assert int(m.group(2)) == 0, m.group(1)
