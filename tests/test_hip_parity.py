@@ -510,6 +510,16 @@ def test_row_strips_over_rows_of_512_pixel_tiles(po):
                         assert np.array_equal(bodies[k], blobs[k][16:]), (tag, k)
                         od, _, _ = po.decode_image(blobs[k])
                         assert np.array_equal(back[k], od), (tag, k)
+                # a stream no encoder writes: small random coefficients, so that nothing leaves the optimistic kernel's proof bound,
+                # and a DIFFERENT lift head in every tile and plane (the lean row-strip kernel de-quantizes per wave: a wave whose
+                # tiles disagree must hand the level to the exact kernel, which de-quantizes per lane)
+                if ci < 3:
+                    body = (nrng.integers(-32768, 32768, (len(blobs[0]) - 16) // 2, dtype=np.int16) // 4096).astype(np.int16)
+                    fake = np.concatenate([blobs[0][:16], body.view(np.uint8)])
+                    od, os_, st = po.decode_image(fake)
+                    assert st == 0
+                    with _with_env(dict(AKO_HIP_PATH=path)):
+                        assert np.array_equal(hip_decode_body(body.view(np.uint8), os_, ch, w, h), od), ("heads", path, w, h, wavelet, wrap, ch, color)
 
 
 def test_shipped_library_ignores_the_measurement_switch(po):
