@@ -28,7 +28,7 @@ with api.Plan(s, 4, w, h) as plan:
 ''' % ROOT
 tiles = sys.argv[1] if len(sys.argv) > 1 else "256"
 for rnd in range(2):
-    for wrap, name in ((0, "CLAMP"), (3, "REPEAT")):
+    for wrap, name in ((0, "CLAMP"), (2, "REPEAT")):
         for pack in ("1", "0"):
             r = subprocess.run([sys.executable, "-c", CHILD, tiles, str(wrap)], env=dict(os.environ, AKO_HIP_PACK=pack), capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]

@@ -440,7 +440,7 @@ def test_small_tiles_packed_into_waves(po):
         for ci, (w, h, tiles) in enumerate(cases):
             for wavelet in (0, 1, 2):
                 ch = int(nrng.choice([4, 4, 3, 1, 2]))
-                wrap = 3 if (ci + wavelet) % 3 == 0 else int(nrng.integers(0, 4))  # (REPEAT, packed since round 4: a third of the cases)
+                wrap = 2 if (ci + wavelet) % 3 == 0 else int(nrng.integers(0, 4))  # (2 = REPEAT, packed since round 4: a third of the cases)
                 q = int(nrng.choice([0, 1, 7, 16, 40]))
                 g = int(nrng.choice([0, 0, 5, 16]))
                 color = int(nrng.choice([0, 0, 1, 2, 3]))
