@@ -204,6 +204,8 @@ struct HEdge
 	bool nh_left, nh_right;  // "wide" strips: the border sits at lane 0 / lane 63, there are no out-of-range lanes on
 	                         // that side to hold the border values (see edge_taps)
 	int lane_first, lane_last;
+	bool bf;         // the border rule of this strip is a plain tap substitution in its first / last lane (CLAMP / ZERO, no out-of-range
+	                 // lanes to patch, no phantom sample): hlift_*() take the branch-free hlift_*_bf() (wave-uniform)
 	bool rep_lanes;  // REPEAT over several tiles in one wave (lane_columns_pack): lane_first / lane_last are THIS lane's tile's, fetched by ds_bpermute
 	int wrap;
 	int perm_prev, perm_next;  // AKO_PERM: 4 * (lane - 1), 4 * (lane + 1) (mod 64): ds_bpermute addresses of the neighbours
@@ -269,6 +271,102 @@ __device__ __forceinline__ BorderVals<V> border_values(V a0, V a1, const HEdge& 
 	return b;
 }
 
+// ---- left / right tile border without control flow (CLAMP and ZERO) -----------------------------------------------
+// fix_halo_lanes() (ako_stream.hip.h) overwrites the lanes BEYOND a border with the nearest in-range value (or zero), per
+// sequence and side, behind a branch: eight row lifts per slot cut the slot into a hundred basic blocks, and a strip at a tile
+// border ran 2.4-3 x the instructions of an interior one.  Its waves -- and, through the lockstep barriers, their whole
+// workgroup -- were the tail of every launch.  The lanes beyond a border are only ever read by ONE lane, the first / last one
+// inside (DD13/7 taps reach two columns = one lane), so here that lane's taps are substituted instead and the lanes beyond
+// compute garbage that nobody reads or stores: three selects per side and row lift on per-lane masks that are simply empty in
+// a strip without that border.  CLAMP: E[-1] := E[0]; HP[-1] = HP[-2] := HP[0]; E[T] = E[T+1] := E[T-1]; HP[T] := HP[T-1]
+// (wavelet-dd137.c:76-79,110-125), ZERO: zeros.  REPEAT strips have no such lanes (they wrap their load addresses,
+// lane_columns()) and run the bodies without border code; MIRROR stays on the general kernels.
+struct HEdgeBF
+{
+	bool first, last;  // this lane holds columns 0,1 / T-2,T-1 of a tile whose border rule is CLAMP or ZERO
+	bool zero;         // W_ZERO
+};
+__device__ __forceinline__ HEdgeBF hedge_bf(const HEdge& he)
+{
+	HEdgeBF e;
+	e.first = (he.left || he.nh_left) && he.first, e.last = (he.right || he.nh_right) && he.last;
+	e.zero = he.wrap == W_ZERO;
+	return e;
+}
+// A neighbour tap that feeds TWO sums: kept as one DPP move whose result the compiler may not fold away again.  Left alone it
+// folds the tap into one of its consumers (a DPP add issues at the rate of a DPP move, half that of a plain add) and still
+// needs the move for the other.
+template <typename V>
+__device__ __forceinline__ V keep_tap(V x)
+{
+	asm("" : "+v"(x));
+	return x;
+}
+// hlift_inverse() / hlift_forward() of ako_stream.hip.h with that border rule (HB = false: none at all)
+template <int KIND, bool HB, typename V>
+__device__ __forceinline__ void hlift_inverse_bf(V L0, V L1, V H0, V H1, const HEdgeBF& e, V& E0, V& O0, V& E1, V& O1)
+{
+	static_assert(KIND != K_HAAR, "lifting wavelets");
+	constexpr bool NRW = std::is_same<V, int>::value;  // the integer pipe wraps to int16 after every step like the reference
+	V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
+	V hL0 = (V)0, hR0 = (V)0;
+	if constexpr (KIND == K_DD137)
+		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : H0, hi = e.zero ? (V)0 : H1;
+		hL1 = e.first ? lo : hL1;
+		if constexpr (KIND == K_DD137)
+			hL0 = e.first ? lo : hL0, hR0 = e.last ? hi : hR0;
+	}
+	E0 = lift_add<NRW>(L0, sum_u<KIND, -1>(hL0, hL1, H0, H1), shift_u<KIND>());
+	E1 = lift_add<NRW>(L1, sum_u<KIND, -1>(hL1, H0, H1, hR0), shift_u<KIND>());
+	V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
+	V eL = (V)0, eR1 = (V)0;
+	if constexpr (KIND == K_DD137)
+		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : E0, hi = e.zero ? (V)0 : E1;
+		eR0 = e.last ? hi : eR0;
+		if constexpr (KIND == K_DD137)
+			eL = e.first ? lo : eL, eR1 = e.last ? hi : eR1;
+	}
+	O0 = lift_add<NRW>(H0, sum_p<KIND, -1>(eL, E0, E1, eR0), shift_p<KIND>());
+	O1 = lift_add<NRW>(H1, sum_p<KIND, -1>(E0, E1, eR0, eR1), shift_p<KIND>());
+}
+template <int KIND, bool HB, typename V, bool NARROW = false>
+__device__ __forceinline__ void hlift_forward_bf(V E0, V O0, V E1, V O1, const HEdgeBF& e, V& L0, V& L1, V& H0, V& H1)
+{
+	static_assert(KIND != K_HAAR, "lifting wavelets");
+	V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
+	V eL = (V)0, eR1 = (V)0;
+	if constexpr (KIND == K_DD137)
+		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : E0, hi = e.zero ? (V)0 : E1;
+		eR0 = e.last ? hi : eR0;
+		if constexpr (KIND == K_DD137)
+			eL = e.first ? lo : eL, eR1 = e.last ? hi : eR1;
+	}
+	H0 = lift_add<NARROW>(O0, sum_p<KIND, +1>(eL, E0, E1, eR0), shift_p<KIND>());
+	H1 = lift_add<NARROW>(O1, sum_p<KIND, +1>(E0, E1, eR0, eR1), shift_p<KIND>());
+	V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
+	V hL0 = (V)0, hR0 = (V)0;
+	if constexpr (KIND == K_DD137)
+		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
+	if constexpr (HB)
+	{
+		const V lo = e.zero ? (V)0 : H0, hi = e.zero ? (V)0 : H1;
+		hL1 = e.first ? lo : hL1;
+		if constexpr (KIND == K_DD137)
+			hL0 = e.first ? lo : hL0, hR0 = e.last ? hi : hR0;
+	}
+	L0 = lift_add<NARROW>(E0, sum_u<KIND, +1>(hL0, hL1, H0, H1), shift_u<KIND>());
+	L1 = lift_add<NARROW>(E1, sum_u<KIND, +1>(hL1, H0, H1, hR0), shift_u<KIND>());
+}
+
 // Horizontal forward lift of one row: samples (E0 O0 E1 O1) of this lane's two coefficient
 // columns -> (L0 L1 H0 H1).  Valid in lanes 2..61.
 template <int KIND, bool NARROW, bool HEDGE, typename V>
@@ -280,6 +378,12 @@ __device__ __forceinline__ void hlift_forward(V E0, V O0, V E1, V O1, const HEdg
 		H0 = nrw<true>(O0 - E0), H1 = nrw<true>(O1 - E1);
 		return;
 	}
+	if constexpr (HEDGE && AKO_PERM == 0 && KIND != K_HAAR)
+		if (ed.bf)  // (wave-uniform) the common border: three selects per side instead of the general rule's branches
+		{
+			hlift_forward_bf<KIND, true, V, NARROW>(E0, O0, E1, O1, hedge_bf(ed), L0, L1, H0, H1);
+			return;
+		}
 	auto LP = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_prev, x); else return from_prev_lane(x); };
 	auto LN = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_next, x); else return from_next_lane(x); };
 	if (HEDGE)
@@ -336,6 +440,12 @@ __device__ __forceinline__ void hlift_inverse(V L0, V L1, V H0, V H1, const HEdg
 		O0 = lift_add<NRW>(L0, H0, 0), O1 = lift_add<NRW>(L1, H1, 0);
 		return;
 	}
+	if constexpr (HEDGE && AKO_PERM == 0 && KIND != K_HAAR)
+		if (ed.bf)
+		{
+			hlift_inverse_bf<KIND, true, V>(L0, L1, H0, H1, hedge_bf(ed), E0, O0, E1, O1);
+			return;
+		}
 	auto LP = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_prev, x); else return from_prev_lane(x); };
 	auto LN = [&](V x) { if constexpr (AKO_PERM != 0) return perm_lane(ed.perm_next, x); else return from_next_lane(x); };
 	if (HEDGE)
@@ -706,6 +816,7 @@ __device__ __forceinline__ LaneCols lane_columns(uint32_t strip, uint32_t strips
 		lc.cs = min(max(lc.c0, 0), Tc - 2);
 	lc.rot = phantom && (lc.cs == Tc - 2);
 	lc.xs = lc.rot ? (W - 4) : (2 * lc.cs);
+	lc.he.bf = (wrap == W_CLAMP || wrap == W_ZERO) && !lc.he.left && !lc.he.right && !phantom && (Tc & 1) == 0;
 	return lc;
 }
 
@@ -761,6 +872,7 @@ __device__ __forceinline__ LaneCols lane_columns_row(uint32_t strip, int lane, i
 	lc.cs = lc.c0;
 	lc.rot = false;
 	lc.xs = 2 * gin;  // the image side: samples counted from the row's first tile
+	lc.he.bf = (wrap == W_CLAMP || wrap == W_ZERO);
 	return lc;
 }
 
@@ -786,6 +898,7 @@ __device__ __forceinline__ LaneCols lane_columns_pack(int lane, int Tc, int wrap
 	lc.cs = lc.c0;
 	lc.rot = false;
 	lc.xs = 2 * lc.c0;
+	lc.he.bf = (wrap == W_CLAMP || wrap == W_ZERO);
 	return lc;
 }
 // ---- helpers of the two-level workgroup kernels (ako_fused.hip.h) ----
@@ -816,6 +929,7 @@ __device__ __forceinline__ LaneCols lane_columns_at(int c_base, int net_lo, int 
 		lc.cs = min(max(lc.c0, 0), Tc - 2);
 	lc.rot = false;
 	lc.xs = 2 * lc.cs;
+	lc.he.bf = false;
 	return lc;
 }
 // vstep_forward() with a ring of THREE for the odd samples as well, so that every ring index has period 3: the level-1
@@ -1760,7 +1874,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5))) vo
 			forward_stream_body<KIND, NPL, U8, NARROW, H, V, DEEP, false>(P, G, id, lc, lane);     \
 	} while (0)
 	(void)cfast;
-	if (lc.hedge)
+	bool hedge_ = lc.hedge;
+#ifdef AKO_EXP_NOHEDGE_I16  // experiment (timing only, wrong values at the left / right borders): border strips on the interior bodies
+	hedge_ = false;
+#endif
+	if (hedge_)
 	{
 		if (vedge)
 			AKO_FWD_BODY(true, true);
@@ -2408,7 +2526,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) vo
 	const LaneCols lc = (!U8 && geom_pack(G)) ? lane_columns_pack(lane, (int)P.sub_w, P.wrap, (int)min(geom_pack(G), P.n_tiles - id.tile))
 	                                        : lane_columns(id.strip, G.strips, geom_wide(G), lane, (int)P.sub_w, (int)P.full_w, P.wrap);
 	const bool vedge = segment_needs_border_code(G, id.seg, (int)P.sub_h);
-	if (lc.hedge)
+	bool hedge_ = lc.hedge;
+#ifdef AKO_EXP_NOHEDGE_I16
+	hedge_ = false;
+#endif
+	if (hedge_)
 	{
 		if (vedge)
 			inverse_stream_body<KIND, NPL, U8, OPT, true, true, DEEP>(P, G, id, lc, lane, xbuf);

@@ -180,101 +180,7 @@ __device__ unsigned long long ako_lean_stamps[2][STAMP_WAVES][12];  // [10], [11
 #define AKO_WAIT_VM(n, K_)
 #endif
 
-// ---- left / right tile border without control flow (CLAMP and ZERO) -----------------------------------------------
-// fix_halo_lanes() (ako_stream.hip.h) overwrites the lanes BEYOND a border with the nearest in-range value (or zero), per
-// sequence and side, behind a branch: eight row lifts per slot cut the slot into a hundred basic blocks, and a strip at a tile
-// border ran 2.4-3 x the instructions of an interior one.  Its waves -- and, through the lockstep barriers, their whole
-// workgroup -- were the tail of every launch.  The lanes beyond a border are only ever read by ONE lane, the first / last one
-// inside (DD13/7 taps reach two columns = one lane), so here that lane's taps are substituted instead and the lanes beyond
-// compute garbage that nobody reads or stores: three selects per side and row lift on per-lane masks that are simply empty in
-// a strip without that border.  CLAMP: E[-1] := E[0]; HP[-1] = HP[-2] := HP[0]; E[T] = E[T+1] := E[T-1]; HP[T] := HP[T-1]
-// (wavelet-dd137.c:76-79,110-125), ZERO: zeros.  REPEAT strips have no such lanes (they wrap their load addresses,
-// lane_columns()) and run the bodies without border code; MIRROR stays on the general kernels.
-struct HEdgeBF
-{
-	bool first, last;  // this lane holds columns 0,1 / T-2,T-1 of a tile whose border rule is CLAMP or ZERO
-	bool zero;         // W_ZERO
-};
-__device__ __forceinline__ HEdgeBF hedge_bf(const HEdge& he)
-{
-	HEdgeBF e;
-	e.first = (he.left || he.nh_left) && he.first, e.last = (he.right || he.nh_right) && he.last;
-	e.zero = he.wrap == W_ZERO;
-	return e;
-}
-// A neighbour tap that feeds TWO sums: kept as one DPP move whose result the compiler may not fold away again.  Left alone it
-// folds the tap into one of its consumers (a DPP add issues at the rate of a DPP move, half that of a plain add) and still
-// needs the move for the other.
-template <typename V>
-__device__ __forceinline__ V keep_tap(V x)
-{
-	asm("" : "+v"(x));
-	return x;
-}
-// hlift_inverse() / hlift_forward() of ako_stream.hip.h with that border rule (HB = false: none at all)
-template <int KIND, bool HB, typename V>
-__device__ __forceinline__ void hlift_inverse_bf(V L0, V L1, V H0, V H1, const HEdgeBF& e, V& E0, V& O0, V& E1, V& O1)
-{
-	static_assert(KIND != K_HAAR, "lifting wavelets");
-	constexpr bool NRW = std::is_same<V, int>::value;  // the integer pipe wraps to int16 after every step like the reference
-	V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
-	V hL0 = (V)0, hR0 = (V)0;
-	if constexpr (KIND == K_DD137)
-		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
-	if constexpr (HB)
-	{
-		const V lo = e.zero ? (V)0 : H0, hi = e.zero ? (V)0 : H1;
-		hL1 = e.first ? lo : hL1;
-		if constexpr (KIND == K_DD137)
-			hL0 = e.first ? lo : hL0, hR0 = e.last ? hi : hR0;
-	}
-	E0 = lift_add<NRW>(L0, sum_u<KIND, -1>(hL0, hL1, H0, H1), shift_u<KIND>());
-	E1 = lift_add<NRW>(L1, sum_u<KIND, -1>(hL1, H0, H1, hR0), shift_u<KIND>());
-	V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
-	V eL = (V)0, eR1 = (V)0;
-	if constexpr (KIND == K_DD137)
-		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
-	if constexpr (HB)
-	{
-		const V lo = e.zero ? (V)0 : E0, hi = e.zero ? (V)0 : E1;
-		eR0 = e.last ? hi : eR0;
-		if constexpr (KIND == K_DD137)
-			eL = e.first ? lo : eL, eR1 = e.last ? hi : eR1;
-	}
-	O0 = lift_add<NRW>(H0, sum_p<KIND, -1>(eL, E0, E1, eR0), shift_p<KIND>());
-	O1 = lift_add<NRW>(H1, sum_p<KIND, -1>(E0, E1, eR0, eR1), shift_p<KIND>());
-}
-template <int KIND, bool HB, typename V>
-__device__ __forceinline__ void hlift_forward_bf(V E0, V O0, V E1, V O1, const HEdgeBF& e, V& L0, V& L1, V& H0, V& H1)
-{
-	static_assert(KIND != K_HAAR, "lifting wavelets");
-	V eR0 = keep_tap(from_next_lane(E0));  // (two sums)
-	V eL = (V)0, eR1 = (V)0;
-	if constexpr (KIND == K_DD137)
-		eL = from_prev_lane(E1), eR1 = from_next_lane(E1);
-	if constexpr (HB)
-	{
-		const V lo = e.zero ? (V)0 : E0, hi = e.zero ? (V)0 : E1;
-		eR0 = e.last ? hi : eR0;
-		if constexpr (KIND == K_DD137)
-			eL = e.first ? lo : eL, eR1 = e.last ? hi : eR1;
-	}
-	H0 = lift_add<false>(O0, sum_p<KIND, +1>(eL, E0, E1, eR0), shift_p<KIND>());
-	H1 = lift_add<false>(O1, sum_p<KIND, +1>(E0, E1, eR0, eR1), shift_p<KIND>());
-	V hL1 = keep_tap(from_prev_lane(H1));  // (two sums)
-	V hL0 = (V)0, hR0 = (V)0;
-	if constexpr (KIND == K_DD137)
-		hL0 = from_prev_lane(H0), hR0 = from_next_lane(H0);
-	if constexpr (HB)
-	{
-		const V lo = e.zero ? (V)0 : H0, hi = e.zero ? (V)0 : H1;
-		hL1 = e.first ? lo : hL1;
-		if constexpr (KIND == K_DD137)
-			hL0 = e.first ? lo : hL0, hR0 = e.last ? hi : hR0;
-	}
-	L0 = lift_add<false>(E0, sum_u<KIND, +1>(hL0, hL1, H0, H1), shift_u<KIND>());
-	L1 = lift_add<false>(E1, sum_u<KIND, +1>(hL1, H0, H1, hR0), shift_u<KIND>());
-}
+// (HEdgeBF, hedge_bf(), keep_tap(), hlift_inverse_bf(), hlift_forward_bf(): in ako_stream.hip.h since the general kernels use them too)
 
 // ---- top / bottom tile border without control flow (CLAMP, REPEAT, ZERO) -------------------------------------------
 // vstep_forward() / vstep_inverse() of ako_stream.hip.h with the border patches as selects on wave-uniform conditions
