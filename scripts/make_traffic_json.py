@@ -14,7 +14,7 @@ KINDS = ["dd137", "cdf53", "haar"]
 
 
 def label(name, workload):
-    m = re.search(r"k_(forward|inverse)_u8_(?:lean|gray)<(\d)", name)  # round 4: the lean / gray level-0 kernels report under the same record names
+    m = re.search(r"k_(forward|inverse)_u8_(?:lean|gray|rows)<(\d)", name)  # round 4: the lean / gray level-0 kernels report under the same record names
     if m:
         return ("fwd" if m.group(1) == "forward" else "inv") + "_stream_" + KINDS[int(m.group(2))] + "_u8:0"
     m = re.search(r"k_(forward|inverse)_stream_u8<(\d)", name)
