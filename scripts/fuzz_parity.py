@@ -14,7 +14,7 @@ t_end = time.time() + budget
 done = 0
 knobs = ["AKO_HIP_PATH", "AKO_HIP_TAIL", "AKO_HIP_OPT", "AKO_HIP_LOCKSTEP", "AKO_HIP_FUSE2", "AKO_HIP_INV_PAIRS", "AKO_HIP_FWD_PAIRS",
          "AKO_HIP_TAIL_MANY", "AKO_HIP_WIDE", "AKO_HIP_STAGED", "AKO_HIP_DEEP", "AKO_KAGARI_THREADS", "AKO_KAGARI_PAR_MIN",
-         "AKO_HIP_GROUP", "AKO_HIP_GROUP_MIN", "AKO_HIP_SEG_ROWS"]
+         "AKO_HIP_GROUP", "AKO_HIP_GROUP_MIN", "AKO_HIP_SEG_ROWS", "AKO_HIP_LEAN", "AKO_HIP_PACK", "AKO_HIP_ROW_STRIPS"]
 while time.time() < t_end:
     for k in knobs:
         os.environ.pop(k, None)
@@ -32,6 +32,9 @@ while time.time() < t_end:
         os.environ["AKO_HIP_TAIL_MANY"] = str(rng.choice([4, 8, 16, 32, 64]))
         os.environ["AKO_HIP_OPT"] = str(rng.integers(0, 2))
         os.environ["AKO_HIP_DEEP"] = str(rng.integers(0, 2))
+        os.environ["AKO_HIP_LEAN"] = str(rng.choice([0, 1, 1]))
+        os.environ["AKO_HIP_PACK"] = str(rng.choice([0, 1, 1]))
+        os.environ["AKO_HIP_ROW_STRIPS"] = str(rng.choice([0, 1, 1]))
         os.environ["AKO_KAGARI_THREADS"] = str(rng.choice([1, 4, 16]))
         os.environ["AKO_KAGARI_PAR_MIN"] = str(rng.choice([256, 4096, 131072]))
         if rng.random() < 0.3:
