@@ -561,9 +561,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #ifdef AKO_EXP_NOHEDGE  // experiments (timing only, wrong pixels at the borders): border strips / segments run the interior bodies
 	hedge_ = false;
 #endif
-#ifdef AKO_EXP_NOVEDGE
-	vedge = false;
-#endif
 	// (strip and segment are the pair's: both its waves take the same way, and execute the same sequence of barriers)
 #define AKO_INV_LEAN(H, V)                                                       \
 	do                                                                           \
@@ -894,9 +891,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
 #ifdef AKO_EXP_NOHEDGE  // experiments (timing only, wrong pixels at the borders): border strips / segments run the interior bodies
 	hedge_ = false;
-#endif
-#ifdef AKO_EXP_NOVEDGE
-	vedge = false;
 #endif
 #define AKO_FWD_LEAN(H, V)                                                   \
 	do                                                                       \
