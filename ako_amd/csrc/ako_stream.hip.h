@@ -1716,9 +1716,15 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 					continue;
 				}
 #endif
+				// the deep variants (no loop: slot K is the K-th of the segment) know their fill slots at compile time: the first
+				// six finish rows of the segment above, nothing of theirs is ever stored -- no gate, no quantizer, no stores
+				if constexpr (DEEP > 0 && K < 6)
+					continue;
 				pack_row_f(lp, hp, gf, rq, w_ll[p], w_c[p], w_b[p], w_d[p]);
 
 			}
+			if constexpr (DEEP > 0 && K < 6)
+				return;
 			if constexpr (GRP)
 			{
 				const bool row_ok = (r >= r_lo) && (r < r_hi);  // the same in every wave of the workgroup
