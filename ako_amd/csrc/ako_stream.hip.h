@@ -1399,6 +1399,9 @@ struct FwdRaw<false>
 // chain: with the running prefetch every slot of such a wave waits for its own round trip to memory, with all
 // loads in flight at once the segment costs one round trip.  (A single pass over exactly N slots: the ring indices
 // of the column pipeline stay compile-time constants for any N.)
+#ifndef AKO_DEEP_FILL_CUT
+#define AKO_DEEP_FILL_CUT 1  // experiments: 0 = the fill slots of the deep forward variants run gate, quantizer and (dropped) stores like every slot
+#endif
 template <int KIND, int NPL, bool U8, bool NARROW, bool HEDGE, bool VEDGE, int DEEP, bool CFAST = false, int PF = 2, int LATE = 0,
           bool MEMONLY = false, int CH = 4, bool GRP = false>
 __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const StreamGeom& G, const UnitId& id,
@@ -1718,12 +1721,12 @@ __device__ __forceinline__ void forward_stream_body(const LevelParams& P, const 
 #endif
 				// the deep variants (no loop: slot K is the K-th of the segment) know their fill slots at compile time: the first
 				// six finish rows of the segment above, nothing of theirs is ever stored -- no gate, no quantizer, no stores
-				if constexpr (DEEP > 0 && K < 6)
+				if constexpr (DEEP > 0 && K < 6 && AKO_DEEP_FILL_CUT)
 					continue;
 				pack_row_f(lp, hp, gf, rq, w_ll[p], w_c[p], w_b[p], w_d[p]);
 
 			}
-			if constexpr (DEEP > 0 && K < 6)
+			if constexpr (DEEP > 0 && K < 6 && AKO_DEEP_FILL_CUT)
 				return;
 			if constexpr (GRP)
 			{
