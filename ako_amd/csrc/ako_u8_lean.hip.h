@@ -255,6 +255,65 @@ __device__ __forceinline__ void vstep_inverse_bf(VInv<V>& s, V LP, V HP, int v, 
 	hA = HP, s.l = LP, eA = Ev;
 }
 
+// ---- CDF5/3 on a pipeline of its own depth -----------------------------------------------------------------------------
+// The ring pipeline above is as deep as DD13/7 needs it (a row leaves three slots after it came in, six slots of every segment only
+// fill it); CDF5/3 through it leaves half the taps unused.  Its own pipeline is one slot deep:
+//   forward:  HP[v-1] = O[v-1] - trunc((E[v-1] + E[v]) / 2),  LP[v-1] = E[v-1] + trunc((HP[v-2] + HP[v-1]) / 4)
+//   inverse:  E[v] = LP[v] - trunc((HP[v-1] + HP[v]) / 4),    O[v-1] = HP[v-1] + trunc((E[v-1] + E[v]) / 2)
+// -- slot v finishes row v - 1, a segment of n rows takes n + 2 slots instead of n + 6, and a column keeps three (two) values
+// instead of eight (seven).  LEAN_LAG is the number of slots between a row coming in and going out.
+#ifndef AKO_CDF_SHALLOW
+#define AKO_CDF_SHALLOW 1  // experiments: 0 = CDF5/3 through the ring pipeline, as before
+#endif
+template <int KIND>
+constexpr int lean_lag()
+{
+	return (KIND == K_CDF53 && AKO_CDF_SHALLOW) ? 1 : 3;
+}
+struct VFwdC
+{
+	float e, o, h;  // E[v-1], O[v-1], HP[v-2]
+};
+template <typename V>
+struct VInvC
+{
+	V h, e;  // HP[v-1], E[v-1]
+};
+// border rules as in vstep_forward_bf: the rows beyond the tile come in through map_index_bf (CLAMP: the nearest, REPEAT: wrapped,
+// ZERO: zeroed by the caller); of the COMPUTED values only HP[-1] is ever asked for: CLAMP HP[-1] := HP[0], ZERO HP[-1] := 0
+template <bool VEDGE>
+__device__ __forceinline__ void vstep_forward_cdf(VFwdC& s, float E, float O, int v, const VEdgeBF& ve, int T, float& lp_out, float& hp_out)
+{
+	(void)T;
+	float H = lift_add<false>(s.o, sum_p<K_CDF53, +1>(0.0f, s.e, E, 0.0f), shift_p<K_CDF53>());  // HP[v-1]
+	float hp = s.h;                                                                             // HP[v-2]
+	if constexpr (VEDGE)
+	{
+		const int u = v - 1;
+		H = (ve.zero && u < 0) ? 0.0f : H;
+		hp = (ve.patch && !ve.zero && u == 0) ? H : hp;
+	}
+	lp_out = lift_add<false>(s.e, sum_u<K_CDF53, +1>(0.0f, hp, H, 0.0f), shift_u<K_CDF53>());
+	hp_out = H;
+	s.e = E, s.o = O, s.h = H;
+}
+// ... and as in vstep_inverse_bf: of the computed values E[T] is asked for (CLAMP E[T] := E[T-1], ZERO E[T] := 0)
+template <bool VEDGE, typename V>
+__device__ __forceinline__ void vstep_inverse_cdf(VInvC<V>& s, V LP, V HP, int v, const VEdgeBF& ve, int T, V& even_out, V& odd_out)
+{
+	constexpr bool NRW = std::is_same<V, int>::value;
+	V Ev = lift_add<NRW>(LP, sum_u<K_CDF53, -1>((V)0, s.h, HP, (V)0), shift_u<K_CDF53>());  // E[v]
+	if constexpr (VEDGE)
+	{
+		const V edge = ve.zero ? (V)0 : s.e;
+		Ev = (ve.patch && v >= T) ? edge : Ev;
+		Ev = (ve.zero && v < 0) ? (V)0 : Ev;
+	}
+	even_out = s.e;                                                                                          // E[v-1]
+	odd_out = lift_add<NRW>(s.h, sum_p<K_CDF53, -1>((V)0, s.e, Ev, (V)0), shift_p<K_CDF53>());              // O[v-1]
+	s.h = HP, s.e = Ev;
+}
+
 // =====================================================================================================================
 // Inverse.  Role 0 carries planes 0, 1 (Y, Co) and finishes the even pixel row of a slot, role 1 planes 2, 3 (Cg, alpha;
 // RGB: Cg alone) and the odd row; the rows' other planes cross through LDS (one barrier per slot, double buffered).
@@ -324,12 +383,18 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 	const uint32_t px_lane_off = store_lane ? (uint32_t)(2 * (ROWS ? (lc.xs >> 1) : lc.c0)) * (uint32_t)CH : OOB;  // (ROWS: the column inside the row of tiles)
 	const float ysc = (P.color == C_YCOCG_Q) ? 0.5f : 1.0f;  // format.c:170: y = in / 2 first
 
-	VInv<float> st[NP][4];
+	constexpr int LAG = lean_lag<KIND>();  // slots between a quadrant row coming in and its two sample rows going out
+	std::conditional_t<LAG == 1, VInvC<float>, VInv<float>> st[NP][4];
 #pragma unroll
 	for (int p = 0; p < NP; p++)
 #pragma unroll
 		for (int k = 0; k < 4; k++)
-			st[p][k] = VInv<float>{{0, 0, 0}, {0, 0, 0}, 0};
+		{
+			if constexpr (LAG == 1)
+				st[p][k] = VInvC<float>{0, 0};
+			else
+				st[p][k] = VInv<float>{{0, 0, 0}, {0, 0, 0}, 0};
+		}
 	float peak_in = 0.0f;
 	const HEdgeBF he = hedge_bf(lc.he);
 	const VEdgeBF ve = {wrap != W_REPEAT, wrap == W_ZERO};
@@ -382,7 +447,12 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 					lpv[k] = zero_row ? 0.0f : lpv[k], hpv[k] = zero_row ? 0.0f : hpv[k];
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				vstep_inverse_bf<KIND, VEDGE, K, float>(st[p][k], lpv[k], hpv[k], v, ve, Tr, ev[p][k], od[p][k]);
+			{
+				if constexpr (LAG == 1)
+					vstep_inverse_cdf<VEDGE, float>(st[p][k], lpv[k], hpv[k], v, ve, Tr, ev[p][k], od[p][k]);
+				else
+					vstep_inverse_bf<KIND, VEDGE, K, float>(st[p][k], lpv[k], hpv[k], v, ve, Tr, ev[p][k], od[p][k]);
+			}
 		}
 	};
 
@@ -448,7 +518,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 #endif
 		AKO_STAMP(4);
 
-		const int r = v - 3, y = 2 * r + ROLE;
+		const int r = v - LAG, y = 2 * r + ROLE;
 		const bool row_ok = (r >= r_lo) && (r < r_hi) && (y < oh);  // wave-uniform; phantom last row dropped (lifting.c:112,141)
 		uint32_t px[4];
 #pragma unroll
@@ -489,14 +559,17 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 
 	// slots v_begin .. r_hi + 2; slot v consumes quadrant row v and finishes sample rows 2 (v - 3), 2 (v - 3) + 1.  The first six
 	// slots finish rows r_lo - 6 .. r_lo - 1, which belong to the segment above (or do not exist): they only fill the pipeline.
-	const int v_begin = r_lo - 3;
-	const int n_slots = r_hi + 3 - v_begin;
+	const int v_begin = r_lo - LAG;
+	const int n_slots = r_hi + LAG - v_begin;
 	// PF row slots are fetched ahead of the one being worked on (the rows exist: segment_needs_border_code() keeps twelve
 	// rows between a body without row border code and the bottom border; VEDGE maps every row into the tile)
 	constexpr int PF = AKO_U8L_INV_PF;
 	static_assert(PF == 1 || PF == 2, "the ring index must repeat with the unrolled row loop");
 	Raw ring[PF + 1];
 	static_for<PF>([&](auto jc) { fetch(v_begin + decltype(jc)::value, ring[decltype(jc)::value]); });
+	// (the one-slot pipeline of CDF5/3 has no trip that only fills it: its first trip is a trip like every other, whose first two
+	// slots finish rows above the segment and drop them)
+	if constexpr (LAG == 3)
 	static_for<6>([&](auto kc) {
 		constexpr int K = decltype(kc)::value;
 		const int v = v_begin + K;
@@ -512,7 +585,7 @@ __device__ __forceinline__ void inverse_u8_lean(const LevelParams& P, const Stre
 			__builtin_amdgcn_raw_buffer_store_b32(0u, rs_img, OOB, 0, 0);
 	});
 	AKO_STAMP_NOW(7);
-	for (int base = 6; base < n_slots; base += 6)
+	for (int base = (LAG == 3) ? 6 : 0; base < n_slots; base += 6)
 	{
 		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
 		{
@@ -682,12 +755,18 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 	}
 	const float ymul = (P.color == C_YCOCG_Q) ? 2.0f : 1.0f;
 
-	VFwd<float> st[NP][4];
+	constexpr int LAG = lean_lag<KIND>();  // slots between a pixel row pair coming in and its sub-band row going out
+	std::conditional_t<LAG == 1, VFwdC, VFwd<float>> st[NP][4];
 #pragma unroll
 	for (int p = 0; p < NP; p++)
 #pragma unroll
 		for (int k = 0; k < 4; k++)
-			st[p][k] = VFwd<float>{{0, 0, 0}, {0, 0}, {0, 0, 0}};
+		{
+			if constexpr (LAG == 1)
+				st[p][k] = VFwdC{0, 0, 0};
+			else
+				st[p][k] = VFwd<float>{{0, 0, 0}, {0, 0}, {0, 0, 0}};
+		}
 	const HEdgeBF he = hedge_bf(lc.he);
 	const VEdgeBF ve = {wrap != W_REPEAT, wrap == W_ZERO};
 	AKO_STAMP_DECL;  // phases: 0 wait for the slot's pixels, 1 pixels -> samples, 2 row pass, 3 column pass, 4 gate + quantizer + pack,
@@ -761,7 +840,12 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 #ifndef AKO_STAMPS_PHASES
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+			{
+				if constexpr (LAG == 1)
+					vstep_forward_cdf<VEDGE>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+				else
+					vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+			}
 #endif
 		}
 #ifdef AKO_STAMPS_PHASES
@@ -773,7 +857,12 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 		AKO_STAMP(2);
 		for (int p = 0; p < NP; p++)
 			for (int k = 0; k < 4; k++)
-				vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+			{
+				if constexpr (LAG == 1)
+					vstep_forward_cdf<VEDGE>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+				else
+					vstep_forward_bf<KIND, VEDGE, K>(st[p][k], e[p][k], o[p][k], v, ve, Tr, lp[p][k], hp[p][k]);
+			}
 		for (int p = 0; p < NP; p++)
 		{
 			AKO_PIN4(lp[p]);
@@ -787,7 +876,7 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 		(void)K;
 		float lp[NP][4], hp[NP][4];
 		lift_slot(kc, v, raw, lp, hp);
-		const int r = v - 3;
+		const int r = v - LAG;
 		const bool row_ok = (r >= r_lo) && (r < r_hi);  // wave-uniform
 		const uint32_t row_grp = (uint32_t)r * sub_pitch_b, row_ll = (uint32_t)r * ll_pitch_b;
 #pragma unroll
@@ -823,13 +912,17 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 
 	// slots v_begin .. r_hi + 2; slot v consumes pixel rows 2 v, 2 v + 1 and finishes sub-band row v - 3.  The first six slots
 	// finish rows r_lo - 6 .. r_lo - 1, which belong to the segment above (or do not exist): no gate, quantizer or stores.
-	const int v_begin = r_lo - 3;
-	const int n_slots = r_hi + 3 - v_begin;
+	const int v_begin = r_lo - LAG;
+	const int n_slots = r_hi + LAG - v_begin;
 	Raw ring;
 	fetch(v_begin, ring);
 	// lockstep: the waves of a workgroup (neighbouring strips, the pair even the same pixels) meet every six slots, so that
 	// what one brought into L2 is still there when its neighbour asks for it (StreamGeom::lockstep; always on here: a branch
 	// around the barrier makes the block behind it a place to sink the first trip's arithmetic into, through scratch)
+	// (the one-slot pipeline of CDF5/3 has no trip that only fills it: its first trip is a trip like every other, whose first two
+	// slots finish rows above the segment and drop them)
+	if constexpr (LAG == 3)
+	{
 	if constexpr (AKO_U8L_LOCKSTEP != 0)
 		__builtin_amdgcn_s_barrier();
 	static_for<6>([&](auto kc) {
@@ -849,7 +942,8 @@ __device__ __forceinline__ void forward_u8_lean(const LevelParams& P, const Stre
 		if constexpr (K == 5)
 			phantom_stores();
 	});
-	for (int base = 6; base < n_slots; base += 6)
+	}
+	for (int base = (LAG == 3) ? 6 : 0; base < n_slots; base += 6)
 	{
 		if constexpr (KIND == K_DD137 && CH == 4)  // (scripts/isa_lint.py finds the loop by this comment)
 		{
